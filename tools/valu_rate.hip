@@ -1,0 +1,145 @@
+// Issue-rate microbenchmark for the gfx950 vector ALU instructions that a modular
+// NTT can be built from.  Prints cycles per wave-instruction per SIMD for each
+// instruction at 1, 2 and 4 waves per SIMD.  Stand-alone diagnostic: not linked
+// into the library.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
+
+constexpr int ITER = 512;
+constexpr int UNROLL = 16;   // instructions per loop body (8 accumulators x 2)
+
+#define BODY8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+
+template <int KIND>
+__global__ void __launch_bounds__(1024) k(unsigned long long* out, double seed, unsigned iseed) {
+    double d[8]; unsigned u[8]; unsigned long long q[8];
+    for (int i = 0; i < 8; i++) { d[i] = seed + i + threadIdx.x; u[i] = iseed * (i + 3) + threadIdx.x; q[i] = u[i]; }
+    double c0 = seed * 0.5, c1 = seed * 0.25;
+    unsigned m0 = iseed | 1, m1 = iseed ^ 0x55aa55aa;
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < ITER; it++) {
+#define F64_FMA(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(c0), "v"(c1));
+#define F64_MUL(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(c0));
+#define F64_ADD(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(c0));
+#define F64_RND(i) asm volatile("v_rndne_f64 %0, %0" : "+v"(d[i]));
+#define F64_CVT(i) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[i]) : "v"(u[i]));
+#define I32_CVT(i) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[i]) : "v"(d[i]));
+#define MUL_LO(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[i]) : "v"(m0));
+#define MUL_HI(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[i]) : "v"(m0));
+#define MAD64(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q[i]) : "v"(u[i]), "v"(m0) : "vcc");
+#define MUL24(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(m0));
+#define MULHI24(i) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(m0));
+#define MAD24(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m0), "v"(m1));
+#define ADD32(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(m0));
+#define ADD3(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m0), "v"(m1));
+#define LSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(u[i]) : "v"(m0));
+#define ADDC(i) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc" : "+v"(u[i]) : "v"(m0), "v"(m1) : "vcc");
+#define CNDM(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(u[i]) : "v"(m0), "v"(m1) : "vcc");
+#define FMA32(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(m0), "v"(m1));
+#define PKFMA32(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d[i]) : "v"(c0), "v"(c1));
+#define DPPMOV(i) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[i]));
+#define DPPADD(i) asm volatile("v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(u[i]) : "v"(m0));
+#define PERM32(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i+1)&7]));
+#define PERM16(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i+1)&7]));
+#define SWZ(i) asm volatile("ds_swizzle_b32 %0, %0 offset:swizzle(SWAP,16)\n\ts_waitcnt lgkmcnt(0)" : "+v"(u[i]));
+#define BPERM(i) asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(u[i]) : "v"(m1));
+#define MOV64(i) asm volatile("v_mov_b64 %0, %1" : "=v"(d[i]) : "v"(c0));
+#define LSHL64(i) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(q[i]));
+#define MAX64(i) asm volatile("v_max_f64 %0, %0, %1" : "+v"(d[i]) : "v"(c0));
+#define FRACT(i) asm volatile("v_fract_f64 %0, %0" : "+v"(d[i]));
+#define FLOOR64(i) asm volatile("v_floor_f64 %0, %0" : "+v"(d[i]));
+#define LDEXP(i) asm volatile("v_ldexp_f64 %0, %0, 3" : "+v"(d[i]));
+#define CMP64(i) asm volatile("v_cmp_lt_f64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(u[i]) : "v"(d[i]), "v"(c0), "v"(m1) : "vcc");
+#define XOR3(i) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(u[i]));
+#define SAD(i) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(u[i]) : "v"(m0));
+#define DOT4(i) asm volatile("v_dot4_i32_i8 %0, %1, %2, %0" : "+v"(u[i]) : "v"(m0), "v"(m1));
+#define RUN(OP) BODY8(OP) BODY8(OP)
+        if constexpr (KIND == 0) { RUN(F64_FMA) }
+        if constexpr (KIND == 1) { RUN(F64_MUL) }
+        if constexpr (KIND == 2) { RUN(F64_ADD) }
+        if constexpr (KIND == 3) { RUN(F64_RND) }
+        if constexpr (KIND == 4) { RUN(F64_CVT) }
+        if constexpr (KIND == 5) { RUN(I32_CVT) }
+        if constexpr (KIND == 6) { RUN(MUL_LO) }
+        if constexpr (KIND == 7) { RUN(MUL_HI) }
+        if constexpr (KIND == 8) { RUN(MAD64) }
+        if constexpr (KIND == 9) { RUN(MUL24) }
+        if constexpr (KIND == 10) { RUN(MULHI24) }
+        if constexpr (KIND == 11) { RUN(MAD24) }
+        if constexpr (KIND == 12) { RUN(ADD32) }
+        if constexpr (KIND == 13) { RUN(ADD3) }
+        if constexpr (KIND == 14) { RUN(LSHLADD) }
+        if constexpr (KIND == 15) { RUN(ADDC) }
+        if constexpr (KIND == 16) { RUN(CNDM) }
+        if constexpr (KIND == 17) { RUN(FMA32) }
+        if constexpr (KIND == 18) { RUN(PKFMA32) }
+        if constexpr (KIND == 19) { RUN(DPPMOV) }
+        if constexpr (KIND == 20) { RUN(DPPADD) }
+        if constexpr (KIND == 21) { RUN(PERM32) }
+        if constexpr (KIND == 22) { RUN(PERM16) }
+        if constexpr (KIND == 23) { RUN(SWZ) }
+        if constexpr (KIND == 24) { RUN(BPERM) }
+        if constexpr (KIND == 25) { RUN(MOV64) }
+        if constexpr (KIND == 26) { RUN(LSHL64) }
+        if constexpr (KIND == 27) { RUN(MAX64) }
+        if constexpr (KIND == 28) { RUN(FRACT) }
+        if constexpr (KIND == 29) { RUN(FLOOR64) }
+        if constexpr (KIND == 30) { RUN(LDEXP) }
+        if constexpr (KIND == 31) { RUN(CMP64) }
+        if constexpr (KIND == 32) { RUN(XOR3) }
+        if constexpr (KIND == 33) { RUN(SAD) }
+        if constexpr (KIND == 34) { RUN(DOT4) }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double s = 0; unsigned us = 0; unsigned long long qs = 0;
+    for (int i = 0; i < 8; i++) { s += d[i]; us ^= u[i]; qs ^= q[i]; }
+    if (s == 1.2345 && us == 77 && qs == 3) out[1] = 1;   // keep results live
+    if ((threadIdx.x & 63) == 0)
+        out[2 + blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+static const char* names[] = {"v_fma_f64","v_mul_f64","v_add_f64","v_rndne_f64","v_cvt_f64_i32","v_cvt_i32_f64",
+  "v_mul_lo_u32","v_mul_hi_u32","v_mad_u64_u32","v_mul_u32_u24","v_mul_hi_u32_u24","v_mad_u32_u24","v_add_u32",
+  "v_add3_u32","v_lshl_add_u32","add_co+addc (2 instr)","cmp+cndmask (2 instr)","v_fma_f32","v_pk_fma_f32","v_mov_b32_dpp",
+  "v_add_u32_dpp","v_permlane32_swap","v_permlane16_swap","ds_swizzle+wait","ds_bpermute+wait","v_mov_b64","v_lshlrev_b64",
+  "v_max_f64","v_fract_f64","v_floor_f64","v_ldexp_f64","cmp_f64+cndmask (2 instr)","v_bfe_u32","v_mul_i32_i24","v_dot4_i32_i8"};
+
+template <int KIND> void run(unsigned long long* dbuf, int ncu) {
+    std::vector<unsigned long long> h(2 + ncu * 16);
+    printf("%-28s", names[KIND]);
+    for (int wps : {1, 2, 4}) {
+        int threads = 64 * 4 * wps;
+        CHECK(hipMemset(dbuf, 0, h.size() * 8));
+        k<KIND><<<ncu, threads>>>(dbuf, 1.000001, 12345u);
+        k<KIND><<<ncu, threads>>>(dbuf, 1.000001, 12345u);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> cyc;
+        for (int b = 0; b < ncu; b++) for (int w = 0; w < 4 * wps; w++) cyc.push_back((double)h[2 + b * 16 + w]);
+        std::sort(cyc.begin(), cyc.end());
+        double med = cyc[cyc.size() / 2];
+        // cycles per wave-instruction per SIMD
+        printf("  wps=%d: %7.2f", wps, med / (double)(ITER * UNROLL) / wps);
+    }
+    printf("\n");
+}
+
+template <int K> void run_all(unsigned long long* d, int ncu) { run<K>(d, ncu); if constexpr (K + 1 < 35) run_all<K + 1>(d, ncu); }
+
+int main() {
+    hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
+    printf("device %s CUs %d clock %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
+    unsigned long long* d; CHECK(hipMalloc(&d, (2 + 1024 * 16) * 8));
+    printf("cycles (s_memtime ticks) per wave64 instruction per SIMD; each kernel: one block per CU\n");
+    run_all<0>(d, p.multiProcessorCount);
+    return 0;
+}
