@@ -1,0 +1,112 @@
+/*
+ * tfhe_amd -- C ABI of the MI355X gate-bootstrapping library.
+ *
+ * The reference (KowerKoint/TFHE) is a header-only C++ template library with no FFI; the
+ * entry points below are what its hot path, HomNAND::nand (reference src/hom_nand.hpp:74-81)
+ * and the functions under it, bind to when evaluation is moved to the GPU.  All pointers are
+ * plain arrays of uint32_t torus words in the flat layouts described next; no C++ or torch
+ * type crosses this boundary.  Every call returns an int status (0 = success) and never
+ * throws.  A context may be used from one host thread at a time.
+ *
+ * Flat layouts (row-major):
+ *   lv0 ciphertext    [n+1]                      = [b, a_0 .. a_{n-1}]   (reference src/hom_nand.hpp:43,
+ *                                                                         src/tlwe.hpp:33-39)
+ *   lv1 ciphertext    [N*K+1]                                            (reference src/trlwe.hpp:109-122)
+ *   bootstrapping key [n][(K+1)*L][K+1][N]       row = comp*L + level    (reference src/hom_nand.hpp:37,
+ *                                                                         src/trgsw.hpp:61-82,119-129)
+ *   key-switching key [N*K][T][1<<base_bit][n+1] slot o = 0 is never read (reference src/hom_nand.hpp:38-41,
+ *                                                                         src/tlwe_key_switching.hpp:26-45)
+ */
+#ifndef TFHE_AMD_H
+#define TFHE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Run-time mirror of the reference's compile-time parameter structs
+ * (src/tlwe.hpp:11-14, src/trlwe.hpp:9-18, src/trgsw.hpp:6-10, src/tlwe_key_switching.hpp:6-9). */
+typedef struct tfhe_amd_params {
+    int32_t n;        /* lv0 TLWE dimension, default 636 */
+    int32_t N;        /* ring degree, default 512 */
+    int32_t K;        /* TRLWE mask polynomials, default 2 */
+    int32_t bg_bit;   /* gadget base bits, default 8 */
+    int32_t L;        /* gadget levels, default 2 */
+    int32_t T;        /* key-switch levels, default 5 */
+    int32_t base_bit; /* key-switch base bits, default 2 */
+} tfhe_amd_params;
+
+enum {
+    TFHE_AMD_OK = 0,
+    TFHE_AMD_ERR_ARGUMENT = 1,    /* null pointer, bad size */
+    TFHE_AMD_ERR_UNSUPPORTED = 2, /* parameter set has no kernel */
+    TFHE_AMD_ERR_HIP = 3,         /* a HIP call failed; see tfhe_amd_last_error */
+    TFHE_AMD_ERR_MEMORY = 4       /* device allocation failed */
+};
+
+typedef struct tfhe_amd_ctx tfhe_amd_ctx;
+
+/* Fills *p with the reference's default parameter set. */
+void tfhe_amd_params_default(tfhe_amd_params* p);
+/* 0 if a kernel exists for *p, else TFHE_AMD_ERR_UNSUPPORTED / TFHE_AMD_ERR_ARGUMENT. */
+int tfhe_amd_params_supported(const tfhe_amd_params* p);
+size_t tfhe_amd_bk_words(const tfhe_amd_params* p);
+size_t tfhe_amd_ks_words(const tfhe_amd_params* p);
+
+/* Replaces holding an EvaluateKey (reference src/hom_nand.hpp:36-42): uploads both keys from
+ * host memory to GPU `device`, transforms the bootstrapping key to the NTT domain, keeps the
+ * key-switching key as is.  The host arrays may be freed after the call. */
+int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk_host, const uint32_t* ks_host, int device,
+                        tfhe_amd_ctx** out);
+/* Same, with both keys already in the memory of GPU `device` (for instance after a broadcast
+ * from another rank).  bk_dev may be freed after the call; ks_dev is copied. */
+int tfhe_amd_ctx_create_device(const tfhe_amd_params* p, const uint32_t* bk_dev, const uint32_t* ks_dev, int device,
+                               tfhe_amd_ctx** out);
+void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx);
+
+/* HomNAND::nand over a batch (reference src/hom_nand.hpp:74-81): out[g] = NAND(a[g], b[g]).
+ * a, b, out: [n_gates][n+1] in HOST memory.  Synchronous. */
+int tfhe_amd_nand_batch(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n_gates);
+/* Same with all three arrays in DEVICE memory; enqueued on `stream` (a hipStream_t, NULL =
+ * the context's own stream) and not synchronised. */
+int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                               size_t n_gates, void* stream);
+
+/* gate_bootstrapping_tlwe_to_tlwe followed by identity_key_switch on pre-combined inputs
+ * (reference src/hom_nand.hpp:79-80): out[g] = KS(bootstrap(c[g])).  The building block
+ * of every other two-input gate. */
+int tfhe_amd_bootstrap_batch(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates);
+int tfhe_amd_bootstrap_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates,
+                                    void* stream);
+
+/* TRGSW::gate_bootstrapping_tlwe_to_tlwe alone (reference src/trgsw.hpp:172-182):
+ * lv1[g] = sample_extract_index(blind_rotate(c[g], bk, testvector), 0).  Device pointers. */
+int tfhe_amd_gate_bootstrapping_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* lv1, size_t n_gates,
+                                             void* stream);
+/* TLWEKeySwitching::identity_key_switch alone (reference src/tlwe_key_switching.hpp:47-65).
+ * Device pointers. */
+int tfhe_amd_identity_key_switch_batch_device(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out,
+                                              size_t n_gates, void* stream);
+
+/* Blocks until everything enqueued on the context's own stream has finished. */
+int tfhe_amd_ctx_synchronize(tfhe_amd_ctx* ctx);
+
+/* Kernel timing with HIP events on the stream the kernels run on.  While enabled, every
+ * batch call records events around its blind-rotation and key-switch kernels.
+ * tfhe_amd_ctx_timing waits for the recorded calls and returns the sums since the last
+ * query: milliseconds in each kernel and the number of batch calls. */
+int tfhe_amd_ctx_enable_timing(tfhe_amd_ctx* ctx, int enable);
+int tfhe_amd_ctx_timing(tfhe_amd_ctx* ctx, double* blind_rotate_ms, double* key_switch_ms, int64_t* calls);
+
+/* Text of the last error recorded on this thread (empty string if none). */
+const char* tfhe_amd_last_error(void);
+/* Library version, "major.minor.patch". */
+const char* tfhe_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,235 @@
+"""ctypes binding of the C ABI declared in include/tfhe_amd.h.
+
+Method names follow the reference's interface for this path: HomNAND::nand
+(reference src/hom_nand.hpp:74-81), TRGSW::gate_bootstrapping_tlwe_to_tlwe
+(src/trgsw.hpp:172-182), TLWEKeySwitching::identity_key_switch
+(src/tlwe_key_switching.hpp:47-65).  Arrays are numpy uint32 on the host or torch uint32/int32
+tensors on the GPU; the binding only passes their addresses.
+"""
+import ctypes as C
+import pathlib
+
+import numpy as np
+
+_HERE = pathlib.Path(__file__).resolve().parent
+_LIB_FILE = _HERE / "libtfhe_amd.so"
+_lib = None
+_load_error = None
+
+
+class TfheAmdError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """Run-time mirror of the reference's parameter structs (src/tlwe.hpp:11-14,
+    src/trlwe.hpp:9-18, src/trgsw.hpp:6-10, src/tlwe_key_switching.hpp:6-9)."""
+    _fields_ = [("n", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("bg_bit", C.c_int32),
+                ("L", C.c_int32), ("T", C.c_int32), ("base_bit", C.c_int32)]
+
+    @property
+    def n1(self):
+        return self.n + 1
+
+    @property
+    def lv1(self):
+        return self.N * self.K
+
+    def bk_shape(self):
+        return (self.n, (self.K + 1) * self.L, self.K + 1, self.N)
+
+    def ks_shape(self):
+        return (self.lv1, self.T, 1 << self.base_bit, self.n + 1)
+
+
+def lib_path():
+    return _LIB_FILE
+
+
+def load_error():
+    """None if the library loaded (or was not tried yet), else the exception text."""
+    return _load_error
+
+
+def library():
+    """The loaded C library.  Raises TfheAmdError if libtfhe_amd.so is absent or unloadable:
+    there is no fallback path."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if not _LIB_FILE.exists():
+        _load_error = f"{_LIB_FILE} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+        raise TfheAmdError(_load_error)
+    try:
+        # torch ships its own HIP runtime (same soname as the system one).  Two runtimes in one
+        # process cannot both own the GPU, so when torch is installed it is imported first and
+        # the library binds to the runtime torch has already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = C.CDLL(str(_LIB_FILE))
+    except OSError as e:  # e.g. no HIP runtime on this machine
+        _load_error = f"cannot load {_LIB_FILE}: {e}"
+        raise TfheAmdError(_load_error) from e
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    pp = C.POINTER(Params)
+    lib.tfhe_amd_params_default.argtypes = [pp]
+    lib.tfhe_amd_params_default.restype = None
+    lib.tfhe_amd_params_supported.argtypes = [pp]
+    lib.tfhe_amd_bk_words.argtypes = [pp]
+    lib.tfhe_amd_bk_words.restype = sz
+    lib.tfhe_amd_ks_words.argtypes = [pp]
+    lib.tfhe_amd_ks_words.restype = sz
+    lib.tfhe_amd_ctx_create.argtypes = [pp, vp, vp, i32, C.POINTER(vp)]
+    lib.tfhe_amd_ctx_create_device.argtypes = [pp, vp, vp, i32, C.POINTER(vp)]
+    lib.tfhe_amd_ctx_destroy.argtypes = [vp]
+    lib.tfhe_amd_ctx_destroy.restype = None
+    lib.tfhe_amd_nand_batch.argtypes = [vp, vp, vp, vp, sz]
+    lib.tfhe_amd_nand_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.tfhe_amd_bootstrap_batch.argtypes = [vp, vp, vp, sz]
+    lib.tfhe_amd_bootstrap_batch_device.argtypes = [vp, vp, vp, sz, vp]
+    lib.tfhe_amd_gate_bootstrapping_batch_device.argtypes = [vp, vp, vp, sz, vp]
+    lib.tfhe_amd_identity_key_switch_batch_device.argtypes = [vp, vp, vp, sz, vp]
+    lib.tfhe_amd_ctx_synchronize.argtypes = [vp]
+    lib.tfhe_amd_ctx_enable_timing.argtypes = [vp, i32]
+    lib.tfhe_amd_ctx_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.tfhe_amd_last_error.restype = C.c_char_p
+    lib.tfhe_amd_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def version():
+    return library().tfhe_amd_version().decode()
+
+
+def params_default():
+    p = Params()
+    library().tfhe_amd_params_default(C.byref(p))
+    return p
+
+
+def _check(rc):
+    if rc != 0:
+        raise TfheAmdError(f"tfhe_amd error {rc}: {library().tfhe_amd_last_error().decode()}")
+
+
+def _host_u32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _dev_ptr(t, words):
+    """Address of a contiguous 4-byte-element torch tensor on the GPU holding `words` elements."""
+    if not (t.is_cuda and t.is_contiguous() and t.element_size() == 4 and t.numel() == words):
+        raise ValueError("expected a contiguous 32-bit GPU tensor of %d elements" % words)
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """Device-resident evaluation key: what holding a HomNAND::EvaluateKey
+    (reference src/hom_nand.hpp:36-42) becomes on the GPU."""
+
+    def __init__(self, params, bk, ks, device=0, keys_on_device=False):
+        lib = library()
+        self.params = params
+        self.device = int(device)
+        self._h = C.c_void_p()
+        if keys_on_device:
+            rc = lib.tfhe_amd_ctx_create_device(C.byref(params), _dev_ptr(bk, lib.tfhe_amd_bk_words(C.byref(params))),
+                                                _dev_ptr(ks, lib.tfhe_amd_ks_words(C.byref(params))), self.device,
+                                                C.byref(self._h))
+        else:
+            bk = _host_u32(bk).reshape(-1)
+            ks = _host_u32(ks).reshape(-1)
+            if bk.size != lib.tfhe_amd_bk_words(C.byref(params)) or ks.size != lib.tfhe_amd_ks_words(C.byref(params)):
+                raise ValueError("key sizes do not match the parameter set")
+            rc = lib.tfhe_amd_ctx_create(C.byref(params), bk.ctypes.data_as(C.c_void_p),
+                                         ks.ctypes.data_as(C.c_void_p), self.device, C.byref(self._h))
+        _check(rc)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            library().tfhe_amd_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- host arrays -------------------------------------------------------
+    def nand(self, a, b):
+        """out[g] = NAND(a[g], b[g]); a, b: [G, n+1] numpy uint32 (reference src/hom_nand.hpp:74-81)."""
+        a, b = _host_u32(a), _host_u32(b)
+        if a.shape != b.shape or a.ndim != 2 or a.shape[1] != self.params.n1:
+            raise ValueError("a and b must both be [G, n+1]")
+        out = np.empty_like(a)
+        _check(library().tfhe_amd_nand_batch(self._h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                             out.ctypes.data_as(C.c_void_p), a.shape[0]))
+        return out
+
+    def bootstrap(self, c):
+        """out[g] = identity_key_switch(gate_bootstrapping_tlwe_to_tlwe(c[g])) (reference src/hom_nand.hpp:79-80)."""
+        c = _host_u32(c)
+        if c.ndim != 2 or c.shape[1] != self.params.n1:
+            raise ValueError("c must be [G, n+1]")
+        out = np.empty_like(c)
+        _check(library().tfhe_amd_bootstrap_batch(self._h, c.ctypes.data_as(C.c_void_p),
+                                                  out.ctypes.data_as(C.c_void_p), c.shape[0]))
+        return out
+
+    # ---- GPU tensors (torch), asynchronous on `stream` (a torch stream or None) -------------
+    @staticmethod
+    def _stream_ptr(stream):
+        return C.c_void_p(stream.cuda_stream) if stream is not None else None
+
+    def nand_device(self, a, b, out, stream=None):
+        g = a.shape[0]
+        w = g * self.params.n1
+        _check(library().tfhe_amd_nand_batch_device(self._h, _dev_ptr(a, w), _dev_ptr(b, w), _dev_ptr(out, w), g,
+                                                    self._stream_ptr(stream)))
+        return out
+
+    def bootstrap_device(self, c, out, stream=None):
+        g = c.shape[0]
+        w = g * self.params.n1
+        _check(library().tfhe_amd_bootstrap_batch_device(self._h, _dev_ptr(c, w), _dev_ptr(out, w), g,
+                                                         self._stream_ptr(stream)))
+        return out
+
+    def gate_bootstrapping_tlwe_to_tlwe_device(self, c, lv1, stream=None):
+        g = c.shape[0]
+        _check(library().tfhe_amd_gate_bootstrapping_batch_device(
+            self._h, _dev_ptr(c, g * self.params.n1), _dev_ptr(lv1, g * (self.params.lv1 + 1)), g,
+            self._stream_ptr(stream)))
+        return lv1
+
+    def identity_key_switch_device(self, lv1, out, stream=None):
+        g = lv1.shape[0]
+        _check(library().tfhe_amd_identity_key_switch_batch_device(
+            self._h, _dev_ptr(lv1, g * (self.params.lv1 + 1)), _dev_ptr(out, g * self.params.n1), g,
+            self._stream_ptr(stream)))
+        return out
+
+    def synchronize(self):
+        _check(library().tfhe_amd_ctx_synchronize(self._h))
+
+    def enable_timing(self, enable=True):
+        _check(library().tfhe_amd_ctx_enable_timing(self._h, 1 if enable else 0))
+
+    def timing(self):
+        """(blind_rotate_ms, key_switch_ms, calls) summed since the previous query."""
+        br, ks, n = C.c_double(), C.c_double(), C.c_int64()
+        _check(library().tfhe_amd_ctx_timing(self._h, C.byref(br), C.byref(ks), C.byref(n)))
+        return br.value, ks.value, n.value

@@ -1,0 +1,21 @@
+// Launcher declarations shared by kernels.hip and the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ntt512.hpp"
+
+namespace tfhe_amd {
+
+hipError_t launch_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, size_t n_gates, int n1,
+                               hipStream_t stream);
+hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint32_t* bk, d2* bk_ntt, int n_polys,
+                                   hipStream_t stream);
+hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
+                                   uint32_t* lv1, int n_gates, int n, int K, int L, hipStream_t stream);
+hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks, uint32_t* out, int n_gates, int n1, int nlv1,
+                             int T, int bb, hipStream_t stream);
+
+}  // namespace tfhe_amd

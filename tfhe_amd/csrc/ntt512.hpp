@@ -1,0 +1,268 @@
+// Device side of the exact negacyclic NTT of length 512 over F_p, p = 6432^4 + 1, evaluated
+// on the FP64 vector pipe of gfx950.
+//
+// Representation: a field element is an integer held exactly in a double, lazily reduced
+// (|x| may grow to a few p between reductions; every bound is stated where it is used and
+// all of them stay below 2^53 = 5.26 p).  A product x*w is reduced with one rounded
+// multiply, one FMA that recovers the rounding error of that multiply exactly, a quotient
+// estimate, and one FMA that subtracts quotient*p exactly:
+//     h = RN(x*w)   l = x*w - h (exact)   q = rint(x * RN(w/p))   r = (h - q*p) + l
+// h - q*p is an integer below 2^53 in magnitude, so both FMAs are exact and r = x*w - q*p.
+//
+// One wave transforms one polynomial: 8 coefficients per lane, three groups of three
+// radix-2 stages done in registers, two transposes through a private LDS buffer between
+// them.  Lane/register <-> position maps (j = position, l = lane, k = register):
+//     layout A: j = 64 k + l                  (stages with distance 256, 128, 64)
+//     layout B: j = 64 (l >> 3) + 8 k + (l & 7)   (distance 32, 16, 8)
+//     layout C: j = 8 l + k                   (distance 4, 2, 1)
+// The forward transform is the merged-twiddle Cooley-Tukey form (natural order in,
+// bit-reversed order out, twiddle psi^bitrev(m+i) for group i of stage m); the inverse is
+// the matching Gentleman-Sande form.  The 1/N factor is folded into the bootstrapping key.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfhe_amd {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// Wave-uniform constants, passed by value as a kernel argument (scalar registers).
+struct NttUniform {
+    double p, pinv;
+    double zI, z;          // zeta^2 = sqrt(-1) and zeta, exact small integers
+    double fw[8], fwp[8];  // forward twiddles of the three layout-A stages, index m+i in 1..7
+    double iw[8], iwp[8];  // inverse twiddles of the three layout-A stages
+    double ninv, ninvp;    // 1/N and RN((1/N)/p), used when the key is transformed
+};
+
+// Per-lane twiddles of one register-resident group of three stages.
+struct Tw7 {
+    double w[7], wp[7];  // [0] distance-4 stage, [1..2] distance-2 stage, [3..6] distance-1 stage
+};
+
+// LDS twiddle block: four sections of 7 (w, wp) pairs per row.
+//   section 0: forward layout B, row = l >> 3   (8 rows)
+//   section 1: forward layout C, row = l        (64 rows)
+//   section 2: inverse layout B                 (8 rows)
+//   section 3: inverse layout C                 (64 rows)
+constexpr int kTwRows = 8 + 64 + 8 + 64;
+constexpr int kTwPairs = kTwRows * 7;  // 1008 pairs = 16128 bytes
+constexpr int kTwFwdB = 0, kTwFwdC = 8 * 7, kTwInvB = (8 + 64) * 7, kTwInvC = (8 + 64 + 8) * 7;
+
+constexpr int kN = 512;
+constexpr int kTrPad = kN + kN / 8;  // transpose buffer, one pad slot per 8 positions
+
+__device__ __forceinline__ int pad_pos(int j) { return j + (j >> 3); }
+
+// x*w mod p, lazily: result = x*w - q*p with |result| <= (0.5 + 0.75 |x| / 2^53) p.
+// Needs |x| < 2^53, |w| <= p/2, wp = RN(w/p).
+__device__ __forceinline__ double mulmod_tw(double x, double w, double wp, double p) {
+    const double q = __builtin_rint(x * wp);
+    const double h = x * w;
+    const double l = __builtin_fma(x, w, -h);
+    const double r = __builtin_fma(-q, p, h);
+    return r + l;
+}
+
+// x*y mod p with both operands variable: result = x*y - q*p, |result| <= (0.5 + 1.5 |x| / 2^53) p.
+// Needs |y| <= p/2 and |x| < 2^53.
+__device__ __forceinline__ double mulmod_var(double x, double y, double p, double pinv) {
+    const double h = x * y;
+    const double l = __builtin_fma(x, y, -h);
+    const double q = __builtin_rint(h * pinv);
+    const double r = __builtin_fma(-q, p, h);
+    return r + l;
+}
+
+// centred residue: |result| <= p/2 (+ one unit when x/p is within rounding of a half-integer)
+__device__ __forceinline__ double reduce(double x, double p, double pinv) {
+    const double q = __builtin_rint(x * pinv);
+    return __builtin_fma(-q, p, x);
+}
+
+__device__ __forceinline__ void bf_ct(double& a, double& b, double w, double wp, double p) {
+    const double t = mulmod_tw(b, w, wp, p);
+    b = a - t;
+    a = a + t;
+}
+
+__device__ __forceinline__ void bf_gs(double& a, double& b, double w, double wp, double p) {
+    const double s = a + b;
+    const double d = a - b;
+    a = s;
+    b = mulmod_tw(d, w, wp, p);
+}
+
+__device__ __forceinline__ void load_tw7(Tw7& t, const d2* row) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        const d2 v = row[i];
+        t.w[i] = v.x;
+        t.wp[i] = v.y;
+    }
+}
+
+// three Cooley-Tukey stages on the 8 registers of a lane: pairs (k, k+4), (k, k+2), (k, k+1)
+template <bool REDUCE_A>
+__device__ __forceinline__ void ct8(double (&x)[8], const Tw7& t, double p, double pinv) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (REDUCE_A) x[k] = reduce(x[k], p, pinv);
+        bf_ct(x[k], x[k + 4], t.w[0], t.wp[0], p);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) bf_ct(x[4 * h + k], x[4 * h + k + 2], t.w[1 + h], t.wp[1 + h], p);
+#pragma unroll
+    for (int g = 0; g < 4; g++) bf_ct(x[2 * g], x[2 * g + 1], t.w[3 + g], t.wp[3 + g], p);
+}
+
+// three Gentleman-Sande stages: pairs (k, k+1), (k, k+2), (k, k+4)
+__device__ __forceinline__ void gs8(double (&x)[8], const Tw7& t, double p) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], t.w[3 + g], t.wp[3 + g], p);
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], t.w[1 + h], t.wp[1 + h], p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], t.w[0], t.wp[0], p);
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS instructions of one wave execute in issue order; this only stops the compiler
+    // from moving them across the exchange point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void transpose_a_to_b(double (&x)[8], double* tr, int lane) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) tr[pad_pos(64 * k + lane)] = x[k];
+    wave_lds_fence();
+    const int base = 72 * (lane >> 3) + (lane & 7);
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = tr[base + 9 * k];
+    wave_lds_fence();
+}
+__device__ __forceinline__ void transpose_b_to_c(double (&x)[8], double* tr, int lane) {
+    const int base = 72 * (lane >> 3) + (lane & 7);
+#pragma unroll
+    for (int k = 0; k < 8; k++) tr[base + 9 * k] = x[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = tr[9 * lane + k];
+    wave_lds_fence();
+}
+__device__ __forceinline__ void transpose_c_to_b(double (&x)[8], double* tr, int lane) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) tr[9 * lane + k] = x[k];
+    wave_lds_fence();
+    const int base = 72 * (lane >> 3) + (lane & 7);
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = tr[base + 9 * k];
+    wave_lds_fence();
+}
+__device__ __forceinline__ void transpose_b_to_a(double (&x)[8], double* tr, int lane) {
+    const int base = 72 * (lane >> 3) + (lane & 7);
+#pragma unroll
+    for (int k = 0; k < 8; k++) tr[base + 9 * k] = x[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = tr[pad_pos(64 * k + lane)];
+    wave_lds_fence();
+}
+
+// Forward transform.  In: layout A, |x| <= 2^31 (SMALL: |x| <= 2^7, 8-bit gadget digits).
+// Out: layout C (bit-reversed spectrum order), |x| <= p/2.
+//
+// Growth between reductions, in units of p (a CT butterfly maps bound B to
+// B + 0.5 + 0.75 B / 5.26): after the layout-A stages <= 1.72, after layout B <= 4.29,
+// the distance-4 stage reduces its additive inputs, after layout C <= 3.2 < 5.26.
+template <bool SMALL>
+__device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform& u, const d2* s_tw,
+                                               double* tr, int lane) {
+    const double p = u.p, pinv = u.pinv;
+    if (SMALL) {
+        // distance 256, twiddle zeta^2 < 2^26: |x * zeta^2| < 2^33, no reduction needed
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double a = x[k], b = x[k + 4];
+            x[k] = __builtin_fma(b, u.zI, a);
+            x[k + 4] = __builtin_fma(-b, u.zI, a);
+        }
+        // distance 128: first half twiddle zeta < 2^13 (|x * zeta| < 2^46, still unreduced and
+        // far below p), second half twiddle zeta^3, reduced
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const double a = x[k], b = x[k + 2];
+            x[k] = __builtin_fma(b, u.z, a);
+            x[k + 2] = __builtin_fma(-b, u.z, a);
+        }
+#pragma unroll
+        for (int k = 4; k < 6; k++) bf_ct(x[k], x[k + 2], u.fw[3], u.fwp[3], p);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) bf_ct(x[k], x[k + 4], u.fw[1], u.fwp[1], p);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) bf_ct(x[4 * h + k], x[4 * h + k + 2], u.fw[2 + h], u.fwp[2 + h], p);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) bf_ct(x[2 * g], x[2 * g + 1], u.fw[4 + g], u.fwp[4 + g], p);
+
+    transpose_a_to_b(x, tr, lane);
+    Tw7 t;
+    load_tw7(t, s_tw + kTwFwdB + 7 * (lane >> 3));
+    ct8<false>(x, t, p, pinv);
+
+    transpose_b_to_c(x, tr, lane);
+    load_tw7(t, s_tw + kTwFwdC + 7 * lane);
+    ct8<true>(x, t, p, pinv);
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+}
+
+// Inverse transform without the 1/N factor.  In: layout C, |x| < 2^53.  Out: layout A,
+// |x| <= 4 p.  Every group of three GS stages starts from |x| <= p/2 and doubles the bound
+// of the sum outputs at most three times.
+__device__ __forceinline__ void ntt512_inverse(double (&x)[8], const NttUniform& u, const d2* s_tw,
+                                               double* tr, int lane) {
+    const double p = u.p, pinv = u.pinv;
+    Tw7 t;
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+    load_tw7(t, s_tw + kTwInvC + 7 * lane);
+    gs8(x, t, p);
+
+    transpose_c_to_b(x, tr, lane);
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+    load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
+    gs8(x, t, p);
+
+    transpose_b_to_a(x, tr, lane);
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+#pragma unroll
+    for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], u.iw[4 + g], u.iwp[4 + g], p);
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], u.iw[2 + h], u.iwp[2 + h], p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], u.iw[1], u.iwp[1], p);
+}
+
+// Centred residue of x (|x| <= 4p, true value known to lie at least 2^43 away from +-p/2)
+// reduced mod 2^32: adding 1.5 * 2^52 leaves the two's-complement integer in the mantissa.
+__device__ __forceinline__ uint32_t to_torus(double x, double p, double pinv) {
+    const double r = reduce(x, p, pinv);
+    return (uint32_t)__double2loint(r + 6755399441055744.0);
+}
+
+}  // namespace tfhe_amd
