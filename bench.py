@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the gate-bootstrapping hot path (HomNAND::nand, reference src/hom_nand.hpp:74-81).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (launched by torch.distributed.run for N > 1).  A step is one batch of
+independent NAND gates per GPU, inputs and outputs resident in HBM.  Keys are generated on
+rank 0, broadcast once over RCCL, and every rank builds its own device context from the
+broadcast copy; there is no collective inside the timed region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import pathlib
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import tfhe_amd  # noqa: E402
+
+# Algorithmic work per gate at the default parameter set: per blind-rotate step 6 forward and
+# 3 inverse length-512 NTTs (2,304 butterflies each) plus 18 length-512 pointwise
+# multiply-accumulates; 636 steps.
+MODMUL_PER_GATE = 636 * (9 * 2304 + 18 * 512)
+BUTTERFLIES_PER_GATE = 636 * 9 * 2304
+MACS_PER_GATE = 636 * 18 * 512
+# FP64 vector instructions per unit in the canonical formulation the kernel uses:
+# a butterfly is one 6-instruction modular multiply plus an add and a subtract, a
+# multiply-accumulate is the 6-instruction multiply plus one add.
+F64_INSTR_PER_GATE = BUTTERFLIES_PER_GATE * 8 + MACS_PER_GATE * 7
+# FP64 vector peak of MI355X: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz (= 78.6 TFLOP/s as FMAs)
+F64_LANE_INSTR_PEAK = 256 * 4 * 16 * 2.4e9
+IO_BYTES_PER_GATE = 3 * 637 * 4
+
+
+def cpu_baseline(params, sample_gates, threads):
+    """The reference itself (oracle/_ref/ref_nand, built from /root/reference in the development
+    container) or, if that binary is absent, the oracle port, timed on this host's cores."""
+    rs = np.random.RandomState(17)
+    n1 = params.n + 1
+    bk = rs.randint(0, 2**32, size=params.bk_shape(), dtype=np.uint64).astype(np.uint32)
+    ks = rs.randint(0, 2**32, size=params.ks_shape(), dtype=np.uint64).astype(np.uint32)
+    ab = rs.randint(0, 2**32, size=(2, sample_gates, n1), dtype=np.uint64).astype(np.uint32)
+    ref_bin = ROOT / "oracle" / "_ref" / "ref_nand"
+    res = {}
+    if ref_bin.exists():
+        with tempfile.TemporaryDirectory() as tmp:
+            t = pathlib.Path(tmp)
+            bk.tofile(t / "bk.bin"); ks.tofile(t / "ks.bin"); ab.tofile(t / "in.bin")
+            out = subprocess.run([str(ref_bin), str(t / "bk.bin"), str(t / "ks.bin"), str(t / "in.bin"),
+                                  str(t / "out.bin"), str(threads)], check=True, capture_output=True, text=True)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+        res = {"value": r["gates_per_s"], "unit": "gates/s", "cores": threads, "kind": "reference",
+               "sample": f"{sample_gates} independent NAND gates, default params, {threads} threads sharing one "
+                         f"EvaluateKey, reference built with g++ -std=gnu++17 -O2; {r['seconds']:.2f} s wall"}
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle_py as O  # checker / baseline only
+
+    octx = O.Context(O.params_default(), bk, ks)
+    t0 = time.time()
+    octx.nand_batch(ab[0], ab[1], threads=threads)
+    dt = time.time() - t0
+    port = {"value": sample_gates / dt, "unit": "gates/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_gates} gates, exact-integer oracle (NTT multiplier), {threads} OpenMP threads; {dt:.2f} s wall"}
+    if not res:
+        return port
+    res["port"] = port
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gates-per-gpu", type=int, default=8192,
+                    help="batch per GPU per step (8192 = one GPU's shard of the 65,536-gate configuration)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-gates", type=int, default=32)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    p = tfhe_amd.params_default()
+    n1, G = p.n + 1, args.gates_per_gpu
+
+    # synthetic keys: uniformly random words of the right shape (the work is data-independent)
+    bk_words, ks_words = int(np.prod(p.bk_shape())), int(np.prod(p.ks_shape()))
+    if rank == 0:
+        rs = np.random.RandomState(2026)
+        bk = torch.from_numpy(rs.randint(-2**31, 2**31, size=bk_words, dtype=np.int64).astype(np.int32)).to(dev)
+        ks = torch.from_numpy(rs.randint(-2**31, 2**31, size=ks_words, dtype=np.int64).astype(np.int32)).to(dev)
+    else:
+        bk = torch.empty(bk_words, dtype=torch.int32, device=dev)
+        ks = torch.empty(ks_words, dtype=torch.int32, device=dev)
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.time()
+        dist.broadcast(bk, src=0)   # RCCL over xGMI, once per key
+        dist.broadcast(ks, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.time() - t0
+    ctx = tfhe_amd.Context(p, bk, ks, device=local_rank, keys_on_device=True)
+    del bk
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    a = torch.randint(-2**31, 2**31 - 1, (G, n1), dtype=torch.int32, device=dev, generator=gen)
+    b = torch.randint(-2**31, 2**31 - 1, (G, n1), dtype=torch.int32, device=dev, generator=gen)
+    out = torch.empty_like(a)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.nand_device(a, b, out)
+    ctx.enable_timing(True)
+    barrier()
+    ctx.timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.nand_device(a, b, out)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
+    barrier()
+    br_ms, ks_ms, calls = ctx.timing()
+    ctx.enable_timing(False)
+    el = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        total_gates = G * world * args.steps
+        value = total_gates / elapsed
+        br_avg_s = br_ms / max(calls, 1) / 1e3
+        achieved = MODMUL_PER_GATE * G / br_avg_s
+        peak = F64_LANE_INSTR_PEAK / (F64_INSTR_PER_GATE / MODMUL_PER_GATE)
+        line = {
+            "metric": "bootstrapped NAND gates/sec (whole node)",
+            "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 torus; NTT over a 51-bit prime evaluated in f64", "data": "synthetic",
+            "config": {"workload": f"{G} independent NAND gates per GPU per step, default params (n=636, N=512, K=2, "
+                                   f"L=2, T=5): one GPU's shard of the 65,536-gate configuration",
+                       "gates_per_gpu": G, "params": "default", "parallelism": f"gate-sharded x{world}, keys replicated"},
+            "roofline": {"bound": "valu_fp64", "kernel": "blind_rotate_512_kernel",
+                         "achieved": achieved / 1e9, "peak": peak / 1e9, "unit": "Gmodmul/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel_ms": br_avg_s * 1e3, "modmul_per_launch": MODMUL_PER_GATE * G,
+                         "key_switch_kernel_ms": ks_ms / max(calls, 1),
+                         "io_GBps": IO_BYTES_PER_GATE * G / (elapsed / args.steps) / 1e9,
+                         "note": "peak = 39.3e12 FP64 lane-instructions/s / 7.69 FP64 instructions per modmul-equivalent"},
+            "key_broadcast_s": t_bcast,
+        }
+        # the 1,024-gate single-GPU configuration and single-gate latency, measured beside it
+        if world == 1:
+            extra = {}
+            for g_small in (1024, 1):
+                ctx.nand_device(a[:g_small], b[:g_small], out[:g_small]); ctx.synchronize()
+                t0 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    ctx.nand_device(a[:g_small], b[:g_small], out[:g_small])
+                ctx.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                extra[f"batch_{g_small}"] = {"ms": dt * 1e3, "gates_per_s": g_small / dt}
+            line["other_batches"] = extra
+            line["single_gate_latency_ms"] = extra["batch_1"]["ms"]
+            if not args.no_cpu_baseline:
+                threads = min(16, os.cpu_count() or 1)
+                line["cpu_baseline"] = cpu_baseline(p, args.cpu_sample_gates, threads)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
