@@ -85,7 +85,7 @@ bool params_sane(const tfhe_amd_params* p) {
 bool blind_rotate_supported(const tfhe_amd_params* p) {
     return p->N == 512 && p->K == 2 && p->L == 2 && p->bg_bit == 8;
 }
-bool key_switch_supported(const tfhe_amd_params* p) { return p->base_bit <= 3 && p->n + 1 <= 1024; }
+bool key_switch_supported(const tfhe_amd_params* p) { return key_switch_has_kernel(p->n + 1, p->T, p->base_bit); }
 
 void build_uniform(NttUniform& u, const TwiddleSet& t) {
     u.p = (double)kP;
@@ -224,22 +224,29 @@ int create_common(const tfhe_amd_params* p, const uint32_t* bk, const uint32_t* 
     CTX_TRY(hipMemcpyAsync(ctx->d_tw, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
 
     const size_t bk_words = tfhe_amd_bk_words(p), ks_words = tfhe_amd_ks_words(p);
+    const int n1 = p->n + 1, nlv1 = p->N * p->K;
     CTX_TRY(hipMalloc(&ctx->d_bk_ntt, bk_words * sizeof(double)));
-    CTX_TRY(hipMalloc(&ctx->d_ks, ks_words * sizeof(uint32_t)));
-    uint32_t* d_bk_raw = nullptr;
-    const uint32_t* bk_src = bk;
+    CTX_TRY(hipMalloc(&ctx->d_ks, key_switch_packed_words(n1, nlv1, p->T, p->base_bit) * sizeof(uint32_t)));
+    // raw keys: uploaded to scratch buffers (host source) or used in place (device source)
+    uint32_t *d_bk_raw = nullptr, *d_ks_raw = nullptr;
+    const uint32_t *bk_src = bk, *ks_src = ks;
+    hipError_t e2 = hipSuccess;
     if (!on_device) {
-        CTX_TRY(hipMalloc(&d_bk_raw, bk_words * sizeof(uint32_t)));
-        hipError_t e1 = hipMemcpyAsync(d_bk_raw, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e1 != hipSuccess) { (void)hipFree(d_bk_raw); CTX_TRY(e1); }
+        e2 = hipMalloc(&d_bk_raw, bk_words * sizeof(uint32_t));
+        if (e2 == hipSuccess) e2 = hipMalloc(&d_ks_raw, ks_words * sizeof(uint32_t));
+        if (e2 == hipSuccess)
+            e2 = hipMemcpyAsync(d_bk_raw, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e2 == hipSuccess)
+            e2 = hipMemcpyAsync(d_ks_raw, ks, ks_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
         bk_src = d_bk_raw;
+        ks_src = d_ks_raw;
     }
-    hipError_t e2 = hipMemcpyAsync(ctx->d_ks, ks, ks_words * sizeof(uint32_t),
-                                   on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream);
     if (e2 == hipSuccess)
         e2 = launch_bk_transform_512(ctx->u, ctx->d_tw, bk_src, ctx->d_bk_ntt, (int)(bk_words / p->N), ctx->stream);
+    if (e2 == hipSuccess) e2 = launch_ks_pack(ctx->d_ks, ks_src, n1, nlv1, p->T, p->base_bit, ctx->stream);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     if (d_bk_raw) (void)hipFree(d_bk_raw);
+    if (d_ks_raw) (void)hipFree(d_ks_raw);
     CTX_TRY(e2);
 #undef CTX_TRY
     *out = ctx;

@@ -175,97 +175,174 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
 }
 
 // ------------------------------------------------------------------------------------------
-// Identity key switch.  A workgroup owns a tile of GT gates and walks the whole table once:
-// for every (i, m) the 2^bb - 1 candidate rows are staged in LDS next to an all-zero row
-// for digit 0, and every gate of the tile subtracts the row its digit selects.  Thread t
-// accumulates words t, t + 256, .. of every gate in registers.
+// Identity key switch.
+//
+// Table layout on the device ("packed"): [N*K][T][2^bb - 1][ROWP] words, the never-read digit-0
+// rows dropped and every row padded to ROWP (a multiple of 320 words) so that rows are
+// 16-byte aligned and the rows of one lv1 coefficient are one contiguous block.
+//
+// Work split: a workgroup (5 waves) owns a tile of 64 gates, a slab of 320 output words and
+// one of `parts` equal slices of the lv1 coefficients.  Lane = gate; wave v accumulates words
+// [64 v, 64 v + 64) of the slab for its 64 gates in registers.  The slab's share of the rows
+// of MG consecutive levels m of one coefficient i is staged in LDS (double buffered, behind
+// one all-zero row); per level every lane turns its own digit into a row address (digit 0 ->
+// the zero row, which is what the reference's `if (o)` amounts to) and reads its 64 words with
+// sixteen 16-byte LDS reads.  Rows are 324 words apart in LDS so that the (at most 2^bb)
+// different rows a 16-lane group touches fall on different banks.  There is no scalar
+// selection and one LDS round trip per level.  With parts > 1 the slices are combined with
+// integer atomic adds into the zero-initialised output; wrap-around addition is associative,
+// so the result does not depend on arrival order.
 // ------------------------------------------------------------------------------------------
-template <int GT, int WPT>
-__global__ void __launch_bounds__(256) key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__ ks,
-                                                         uint32_t* __restrict__ out, int n_gates, int n1, int nlv1,
-                                                         int T, int bb) {
-    constexpr int ROW = 256 * WPT;  // padded row length in words
-    constexpr int CHUNK = 256;      // lv1 coefficients whose digits are resident at a time
+constexpr int kKsThreads = 320;   // 5 waves
+constexpr int kKsSlab = 320;      // output words per workgroup
+constexpr int kKsRowLds = 324;    // LDS row stride in words: 320 + 4 (bank skew between rows)
+constexpr int kKsChunk = 64;      // lv1 coefficients whose digits are resident at a time
+constexpr int kKsTile = 64;       // gates per workgroup = lanes per wave
+
+__global__ void __launch_bounds__(256)
+ks_pack_kernel(uint32_t* __restrict__ packed, const uint32_t* __restrict__ ks, size_t rows_out, int nr1, int n1,
+               int rowp) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows_out * (size_t)rowp) return;
+    const size_t row = e / rowp;
+    const int w = (int)(e - row * rowp);
+    const size_t im = row / nr1;
+    const int o = (int)(row - im * nr1) + 1;
+    packed[e] = w < n1 ? ks[(im * (nr1 + 1) + o) * n1 + w] : 0u;
+}
+
+template <int NR1, int MG>
+__global__ void __launch_bounds__(kKsThreads, 3)
+key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__ ks_packed,
+                  uint32_t* __restrict__ out, int n_gates, int n1, int nlv1, int T, int bb, int rowp, int parts) {
+    constexpr int SR = MG * NR1;                          // rows per stage
+    constexpr int STAGE_V4 = SR * kKsSlab / 4;            // 16-byte vectors per stage
+    constexpr int PRE = (STAGE_V4 + kKsThreads - 1) / kKsThreads;
+    constexpr int BUF = SR * kKsRowLds;                   // words per stage buffer
     extern __shared__ uint32_t s_mem[];
-    const int nrows = 1 << bb;
-    uint32_t* s_dig = s_mem;                    // [CHUNK][GT]
-    uint32_t* s_rows = s_mem + CHUNK * GT;      // [2][nrows][ROW]
-    const int tid = threadIdx.x;
-    const int g0 = blockIdx.x * GT;
+    uint32_t* s_zero = s_mem;                             // [kKsRowLds] all-zero row
+    uint32_t* s_rows = s_mem + kKsRowLds;                 // [2][SR][kKsRowLds]
+    uint32_t* s_dig = s_rows + 2 * BUF;                   // [kKsChunk][kKsTile] digit words
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slabs = rowp / kKsSlab;
+    int b = blockIdx.x;
+    const int part = b % parts; b /= parts;
+    const int slab = b % slabs; b /= slabs;
+    const int g0 = b * kKsTile;
+    const int i_begin = (int)((long)nlv1 * part / parts), i_end = (int)((long)nlv1 * (part + 1) / parts);
     const uint32_t round_offset = 1u << (32 - T * bb - 1);
     const int dshift = 32 - T * bb;
-    const uint32_t omask = (uint32_t)nrows - 1;
+    const uint32_t omask = (1u << bb) - 1;
 
-    uint32_t acc[GT][WPT];
+    uint32_t acc[64];
 #pragma unroll
-    for (int g = 0; g < GT; g++)
-#pragma unroll
-        for (int w = 0; w < WPT; w++) acc[g][w] = 0u;
+    for (int k = 0; k < 64; k++) acc[k] = 0u;
+    for (int w = tid; w < kKsRowLds; w += kKsThreads) s_zero[w] = 0u;
 
-    // the zero rows of both buffers
-    for (int b = 0; b < 2; b++)
-        for (int w = tid; w < ROW; w += 256) s_rows[(b * nrows) * ROW + w] = 0u;
+    const int stages_per_i = T / MG;
+    const int total = (i_end - i_begin) * stages_per_i;
+    static_assert(PRE <= 4, "stage too large for the prefetch registers");
+    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {};
+    // threads past the end of the stage re-read its last vector (never stored)
+#define KS_LOAD1(Q, DST)                                                                       \
+    if (Q < PRE) {                                                                             \
+        const int e_ = min(tid + Q * kKsThreads, STAGE_V4 - 1);                                \
+        const int r_ = e_ / (kKsSlab / 4), c_ = e_ - r_ * (kKsSlab / 4);                       \
+        DST = *reinterpret_cast<const uint4*>(src_ + (size_t)r_ * rowp + 4 * c_);              \
+    }
+#define KS_PREFETCH(ST)                                                                        \
+    {                                                                                          \
+        const int pi_ = i_begin + (ST) / stages_per_i, pm_ = ((ST) % stages_per_i) * MG;       \
+        const uint32_t* src_ = ks_packed + ((size_t)pi_ * T + pm_) * NR1 * rowp + slab * kKsSlab; \
+        KS_LOAD1(0, pre0) KS_LOAD1(1, pre1) KS_LOAD1(2, pre2) KS_LOAD1(3, pre3)                \
+    }
+#define KS_STORE1(Q, SRC)                                                                      \
+    if (Q < PRE) {                                                                             \
+        const int e_ = tid + Q * kKsThreads;                                                   \
+        if (e_ < STAGE_V4) {                                                                   \
+            const int r_ = e_ / (kKsSlab / 4), c_ = e_ - r_ * (kKsSlab / 4);                   \
+            *reinterpret_cast<uint4*>(buf + r_ * kKsRowLds + 4 * c_) = SRC;                    \
+        }                                                                                      \
+    }
 
-    uint32_t pre[7][WPT];  // rows 1 .. nrows-1 of the next (i, m); nrows <= 8
-    auto prefetch = [&](int i, int m) {
-        const uint32_t* base = ks + ((size_t)i * T + m) * nrows * n1;
-#pragma unroll
-        for (int o = 1; o < 8; o++)
-            if (o < nrows)
-#pragma unroll
-                for (int w = 0; w < WPT; w++) {
-                    const int word = tid + 256 * w;
-                    pre[o - 1][w] = word < n1 ? base[(size_t)o * n1 + word] : 0u;
-                }
-    };
-
-    const int total = nlv1 * T;
-    prefetch(0, 0);
-    for (int idx = 0; idx < total; idx++) {
-        const int i = idx / T, m = idx - i * T;
-        if (m == 0 && (i % CHUNK) == 0) {
-            __syncthreads();  // previous chunk's digits are no longer read
-            const int ic = i + tid;
-#pragma unroll 4
-            for (int g = 0; g < GT; g++) {
+    if (total > 0) KS_PREFETCH(0)
+    for (int st = 0; st < total; st++) {
+        const int irel = st / stages_per_i, m0 = (st - irel * stages_per_i) * MG;
+        if (m0 == 0 && (irel % kKsChunk) == 0) {
+            __syncthreads();  // the previous chunk's digits are no longer read
+            for (int e = tid; e < kKsChunk * kKsTile; e += kKsThreads) {
+                const int ii = e % kKsChunk, g = e / kKsChunk;
+                const int i = i_begin + irel + ii;
                 uint32_t v = 0u;
-                if (g0 + g < n_gates && ic < nlv1) v = lv1[(size_t)(g0 + g) * (nlv1 + 1) + 1 + ic];
-                s_dig[tid * GT + g] = (v + round_offset) >> dshift;
+                if (g0 + g < n_gates && i < i_end) v = lv1[(size_t)(g0 + g) * (nlv1 + 1) + 1 + i];
+                s_dig[ii * kKsTile + g] = (v + round_offset) >> dshift;
             }
         }
-        uint32_t* buf = s_rows + (size_t)(idx & 1) * nrows * ROW;
-#pragma unroll
-        for (int o = 1; o < 8; o++)
-            if (o < nrows)
-#pragma unroll
-                for (int w = 0; w < WPT; w++) buf[o * ROW + tid + 256 * w] = pre[o - 1][w];
-        __syncthreads();
-        if (idx + 1 < total) prefetch((idx + 1) / T, (idx + 1) % T);
+        uint32_t* buf = s_rows + (st & 1) * BUF;
+        KS_STORE1(0, pre0) KS_STORE1(1, pre1) KS_STORE1(2, pre2) KS_STORE1(3, pre3)
+        __syncthreads();  // stage st is in LDS; all reads of stage st-1 precede the next write of its buffer
+        if (st + 1 < total) KS_PREFETCH(st + 1)
 
-        const int oshift = (T - 1 - m) * bb;
-        const uint32_t* dig = s_dig + (i % CHUNK) * GT;
+        const uint32_t d = s_dig[(irel % kKsChunk) * kKsTile + lane];
+        // byte offsets from s_zero: word 64*wave of the zero row, or of row (mm*NR1 + o - 1) of buf
+        const int zero_off = 4 * 64 * wave;
+        const int buf_off = 4 * ((int)(buf - s_zero) + 64 * wave);
+        const char* base = reinterpret_cast<const char*>(s_zero);
 #pragma unroll
-        for (int g = 0; g < GT; g++) {
-            const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)dig[g]);
-            const uint32_t o = (d >> oshift) & omask;
-            const uint32_t* row = buf + o * ROW + tid;
+        for (int mm = 0; mm < MG; mm++) {
+            const uint32_t o = (d >> ((T - 1 - (m0 + mm)) * bb)) & omask;
+            const int off = o ? buf_off + 4 * kKsRowLds * (mm * NR1 + (int)o - 1) : zero_off;
+            const uint4* row = reinterpret_cast<const uint4*>(base + off);
+            // two batches of eight 16-byte reads; the scheduling barriers keep the compiler from
+            // hoisting later batches' reads (and their 32 registers each) above this one
 #pragma unroll
-            for (int w = 0; w < WPT; w++) acc[g][w] -= row[256 * w];
+            for (int h = 0; h < 2; h++) {
+                uint4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = row[8 * h + q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    acc[32 * h + 4 * q] -= v[q].x;
+                    acc[32 * h + 4 * q + 1] -= v[q].y;
+                    acc[32 * h + 4 * q + 2] -= v[q].z;
+                    acc[32 * h + 4 * q + 3] -= v[q].w;
+                }
+                // opaque to the optimiser: stops it from summing several levels' rows first
+                // (which would keep all of them live) before touching the accumulators
+#pragma unroll
+                for (int k = 0; k < 32; k++) asm volatile("" : "+v"(acc[32 * h + k]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
-    // out = (b, 0, ..) - sum
+#undef KS_PREFETCH
+#undef KS_LOAD1
+#undef KS_STORE1
+
+    // Epilogue: out (+)= (b, 0, ..) - sum, transposed through a per-wave LDS tile so that
+    // consecutive lanes touch consecutive words.
+    __syncthreads();
+    uint32_t* s_t = s_mem + wave * (64 * 17);
+    const int wbase = slab * kKsSlab + 64 * wave;
 #pragma unroll
-    for (int g = 0; g < GT; g++) {
-        if (g0 + g >= n_gates) break;
+    for (int pass = 0; pass < 4; pass++) {
 #pragma unroll
-        for (int w = 0; w < WPT; w++) {
-            const int word = tid + 256 * w;
-            if (word >= n1) continue;
-            uint32_t v = acc[g][w];
-            if (word == 0) v += lv1[(size_t)(g0 + g) * (nlv1 + 1)];
-            out[(size_t)(g0 + g) * n1 + word] = v;
+        for (int k = 0; k < 16; k++) s_t[lane * 17 + k] = acc[16 * pass + k];
+        wave_lds_fence();
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int gl = it * 4 + (lane >> 4), k = lane & 15;
+            uint32_t v = s_t[gl * 17 + k];
+            const int word = wbase + 16 * pass + k, g = g0 + gl;
+            if (g < n_gates && word < n1) {
+                if (word == 0 && part == 0) v += lv1[(size_t)g * (nlv1 + 1)];
+                uint32_t* dst = out + (size_t)g * n1 + word;
+                if (parts == 1) *dst = v;
+                else if (v != 0u) atomicAdd(dst, v);
+            }
         }
+        wave_lds_fence();
     }
 }
 
@@ -299,35 +376,56 @@ hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* 
     return hipGetLastError();
 }
 
-size_t key_switch_lds_bytes(int gt, int wpt, int bb) {
-    return sizeof(uint32_t) * ((size_t)256 * gt + (size_t)2 * (1 << bb) * 256 * wpt);
+template <int NR1, int MG>
+static hipError_t launch_key_switch_inst(const uint32_t* lv1, const uint32_t* ks_packed, uint32_t* out, int n_gates,
+                                         int n1, int nlv1, int T, int bb, hipStream_t stream) {
+    const size_t lds = sizeof(uint32_t) * ((size_t)(1 + 2 * MG * NR1) * kKsRowLds + (size_t)kKsChunk * kKsTile);
+    hipError_t e = hipFuncSetAttribute((const void*)key_switch_kernel<NR1, MG>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int rowp = key_switch_row_words(n1);
+    const int tiles = (n_gates + kKsTile - 1) / kKsTile, slabs = rowp / kKsSlab;
+    // slices of the lv1 range: aim at two workgroups per CU, never finer than one digit chunk
+    int parts = 1;
+    while (tiles * slabs * parts * 2 <= 512 && parts * 2 * kKsChunk <= nlv1) parts *= 2;
+    if (parts > 1) {
+        e = hipMemsetAsync(out, 0, (size_t)n_gates * n1 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
+    key_switch_kernel<NR1, MG><<<(unsigned)(tiles * slabs * parts), kKsThreads, lds, stream>>>(
+        lv1, ks_packed, out, n_gates, n1, nlv1, T, bb, rowp, parts);
+    return hipGetLastError();
 }
 
-hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks, uint32_t* out, int n_gates, int n1, int nlv1,
-                             int T, int bb, hipStream_t stream) {
-    if (n_gates == 0) return hipSuccess;
-    if (bb < 1 || bb > 3 || T * bb > 31 || n1 > 1024) return hipErrorInvalidValue;
-    const int wpt = (n1 + 255) / 256;
-    constexpr int GT = 32;
-    const unsigned blocks = (unsigned)((n_gates + GT - 1) / GT);
-    const size_t lds = key_switch_lds_bytes(GT, wpt, bb);
-#define KS_CASE(W)                                                                                              \
-    case W: {                                                                                                   \
-        hipError_t e = hipFuncSetAttribute((const void*)key_switch_kernel<GT, W>,                               \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-        if (e != hipSuccess) return e;                                                                          \
-        key_switch_kernel<GT, W><<<blocks, 256, lds, stream>>>(lv1, ks, out, n_gates, n1, nlv1, T, bb);          \
-        break;                                                                                                  \
-    }
-    switch (wpt) {
-        KS_CASE(1)
-        KS_CASE(2)
-        KS_CASE(3)
-        KS_CASE(4)
-        default: return hipErrorInvalidValue;
-    }
-#undef KS_CASE
+bool key_switch_has_kernel(int n1, int T, int bb) {
+    if (bb < 1 || bb > 3 || T < 1 || T * bb > 31) return false;
+    return n1 >= 1;
+}
+
+int key_switch_row_words(int n1) { return (n1 + kKsSlab - 1) / kKsSlab * kKsSlab; }
+
+size_t key_switch_packed_words(int n1, int nlv1, int T, int bb) {
+    return (size_t)nlv1 * T * ((1 << bb) - 1) * key_switch_row_words(n1);
+}
+
+hipError_t launch_ks_pack(uint32_t* packed, const uint32_t* ks, int n1, int nlv1, int T, int bb, hipStream_t stream) {
+    const int nr1 = (1 << bb) - 1, rowp = key_switch_row_words(n1);
+    const size_t rows = (size_t)nlv1 * T * nr1, total = rows * rowp;
+    ks_pack_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(packed, ks, rows, nr1, n1, rowp);
     return hipGetLastError();
+}
+
+hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks_packed, uint32_t* out, int n_gates, int n1,
+                             int nlv1, int T, int bb, hipStream_t stream) {
+    if (n_gates == 0) return hipSuccess;
+    if (!key_switch_has_kernel(n1, T, bb)) return hipErrorInvalidValue;
+    // MG levels per LDS stage: the largest instantiated divisor of T
+#define KS_GO(NR1, MG) return launch_key_switch_inst<NR1, MG>(lv1, ks_packed, out, n_gates, n1, nlv1, T, bb, stream)
+    if (bb == 1) { if (T % 5 == 0) KS_GO(1, 5); if (T % 4 == 0) KS_GO(1, 4); KS_GO(1, 1); }
+    if (bb == 2) { if (T % 5 == 0) KS_GO(3, 5); if (T % 4 == 0) KS_GO(3, 4); KS_GO(3, 1); }
+    if (T % 2 == 0) KS_GO(7, 2);
+    KS_GO(7, 1);
+#undef KS_GO
 }
 
 }  // namespace tfhe_amd

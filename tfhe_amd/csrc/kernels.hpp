@@ -15,7 +15,13 @@ hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint
                                    hipStream_t stream);
 hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
                                    uint32_t* lv1, int n_gates, int n, int K, int L, hipStream_t stream);
-hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks, uint32_t* out, int n_gates, int n1, int nlv1,
-                             int T, int bb, hipStream_t stream);
+bool key_switch_has_kernel(int n1, int T, int bb);
+// the key-switching key is kept on the device without its digit-0 rows, rows padded to
+// key_switch_row_words(n1) words
+int key_switch_row_words(int n1);
+size_t key_switch_packed_words(int n1, int nlv1, int T, int bb);
+hipError_t launch_ks_pack(uint32_t* packed, const uint32_t* ks, int n1, int nlv1, int T, int bb, hipStream_t stream);
+hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks_packed, uint32_t* out, int n_gates, int n1,
+                             int nlv1, int T, int bb, hipStream_t stream);
 
 }  // namespace tfhe_amd
