@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports every symbol include/tfhe_amd.h declares; argument
+checking that needs no GPU."""
+import ctypes as C
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+import tfhe_amd
+
+HEADER = pathlib.Path(__file__).resolve().parent.parent / "include" / "tfhe_amd.h"
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(tfhe_amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ["tfhe_amd_ctx_create", "tfhe_amd_ctx_create_device", "tfhe_amd_ctx_destroy", "tfhe_amd_nand_batch",
+                 "tfhe_amd_nand_batch_device", "tfhe_amd_bootstrap_batch", "tfhe_amd_bootstrap_batch_device",
+                 "tfhe_amd_gate_bootstrapping_batch_device", "tfhe_amd_identity_key_switch_batch_device"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = tfhe_amd.library()  # raises if the .so is missing: there is no fallback
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+
+
+def test_params_and_sizes():
+    p = tfhe_amd.params_default()
+    assert (p.n, p.N, p.K, p.bg_bit, p.L, p.T, p.base_bit) == (636, 512, 2, 8, 2, 5, 2)
+    lib = tfhe_amd.library()
+    assert lib.tfhe_amd_bk_words(C.byref(p)) == 636 * 6 * 3 * 512      # 23,445,504 bytes
+    assert lib.tfhe_amd_ks_words(C.byref(p)) == 1024 * 5 * 4 * 637     # 52,183,040 bytes
+    assert lib.tfhe_amd_params_supported(C.byref(p)) == 0
+    bad = tfhe_amd.Params(636, 500, 2, 8, 2, 5, 2)  # ring degree not a power of two
+    assert lib.tfhe_amd_params_supported(C.byref(bad)) == 1
+    bad = tfhe_amd.Params(636, 512, 2, 8, 4, 5, 2)  # L * bg_bit > 31
+    assert lib.tfhe_amd_params_supported(C.byref(bad)) == 1
+    assert tfhe_amd.version().count(".") == 2
+
+
+def test_argument_errors_without_gpu():
+    lib = tfhe_amd.library()
+    p = tfhe_amd.params_default()
+    h = C.c_void_p()
+    assert lib.tfhe_amd_ctx_create(C.byref(p), None, None, 0, C.byref(h)) == 1
+    assert b"null" in lib.tfhe_amd_last_error()
+    assert lib.tfhe_amd_nand_batch(None, None, None, None, 4) == 1
+    with pytest.raises(ValueError):
+        tfhe_amd.Context(p, np.zeros(3, np.uint32), np.zeros(3, np.uint32))
