@@ -51,20 +51,24 @@ typedef struct tfhe_amd_ctx tfhe_amd_ctx;
 
 /* Fills *p with the reference's default parameter set. */
 void tfhe_amd_params_default(tfhe_amd_params* p);
-/* 0 if a kernel exists for *p, else TFHE_AMD_ERR_UNSUPPORTED / TFHE_AMD_ERR_ARGUMENT. */
+/* 0 if kernels exist for *p, else TFHE_AMD_ERR_UNSUPPORTED / TFHE_AMD_ERR_ARGUMENT. */
 int tfhe_amd_params_supported(const tfhe_amd_params* p);
 size_t tfhe_amd_bk_words(const tfhe_amd_params* p);
 size_t tfhe_amd_ks_words(const tfhe_amd_params* p);
 
-/* Replaces holding an EvaluateKey (reference src/hom_nand.hpp:36-42): uploads both keys from
- * host memory to GPU `device`, transforms the bootstrapping key to the NTT domain, keeps the
- * key-switching key as is.  The host arrays may be freed after the call. */
-int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk_host, const uint32_t* ks_host, int device,
-                        tfhe_amd_ctx** out);
-/* Same, with both keys already in the memory of GPU `device` (for instance after a broadcast
- * from another rank).  bk_dev may be freed after the call; ks_dev is copied. */
-int tfhe_amd_ctx_create_device(const tfhe_amd_params* p, const uint32_t* bk_dev, const uint32_t* ks_dev, int device,
-                               tfhe_amd_ctx** out);
+enum {
+    TFHE_AMD_CTX_DEFAULT = 0,
+    TFHE_AMD_CTX_KEYS_ON_DEVICE = 1,  /* bk / ks point to memory of GPU `device` (e.g. after a broadcast) */
+    TFHE_AMD_CTX_GENERIC_KERNELS = 2  /* use the parameter-generic exact O(N^2) kernels even where a
+                                         specialised NTT kernel exists (cross-checking) */
+};
+
+/* Replaces holding an EvaluateKey (reference src/hom_nand.hpp:36-42): uploads the keys to GPU
+ * `device`, transforms the bootstrapping key to the NTT domain (specialised parameter sets) and
+ * re-packs the key-switching key.  The caller's arrays may be freed after the call.  Either
+ * key may be NULL; the stages that need it then return TFHE_AMD_ERR_ARGUMENT. */
+int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint32_t* ks, int device,
+                        unsigned flags, tfhe_amd_ctx** out);
 void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx);
 
 /* HomNAND::nand over a batch (reference src/hom_nand.hpp:74-81): out[g] = NAND(a[g], b[g]).
@@ -83,13 +87,29 @@ int tfhe_amd_bootstrap_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32
                                     void* stream);
 
 /* TRGSW::gate_bootstrapping_tlwe_to_tlwe alone (reference src/trgsw.hpp:172-182):
- * lv1[g] = sample_extract_index(blind_rotate(c[g], bk, testvector), 0).  Device pointers. */
+ * lv1[g] = sample_extract_index(blind_rotate(c[g], bk, testvector), 0); lv1: [n_gates][N*K+1]. */
+int tfhe_amd_gate_bootstrapping_batch(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* lv1, size_t n_gates);
 int tfhe_amd_gate_bootstrapping_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* lv1, size_t n_gates,
                                              void* stream);
-/* TLWEKeySwitching::identity_key_switch alone (reference src/tlwe_key_switching.hpp:47-65).
- * Device pointers. */
+/* TRGSW::blind_rotate (reference src/trgsw.hpp:131-170): acc[g] = CMUX chain over c[g] starting
+ * from test_vector * X^(-floor(b 2N)).  test_vector: [K+1][N] shared by all gates, NULL = the
+ * gate-bootstrapping one.  acc: [n_gates][K+1][N]. */
+int tfhe_amd_blind_rotate_batch(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* test_vector, uint32_t* acc,
+                                size_t n_gates);
+int tfhe_amd_blind_rotate_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* test_vector,
+                                       uint32_t* acc, size_t n_gates, void* stream);
+/* TLWEKeySwitching::identity_key_switch alone (reference src/tlwe_key_switching.hpp:47-65). */
+int tfhe_amd_identity_key_switch_batch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t n_gates);
 int tfhe_amd_identity_key_switch_batch_device(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out,
                                               size_t n_gates, void* stream);
+
+/* TRGSW::external_product / TRGSW::cmux on explicit operands (reference src/trgsw.hpp:100-117),
+ * no context: trgsw [batch][(K+1)L][K+1][N], TRLWE operands and out [batch][K+1][N], all in HOST
+ * memory; evaluated on GPU `device`.  cmux: out = trgsw (x) (d1 - d0) + d0. */
+int tfhe_amd_external_product_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* trlwe,
+                                    uint32_t* out, size_t batch, int device);
+int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* d0, const uint32_t* d1,
+                        uint32_t* out, size_t batch, int device);
 
 /* Blocks until everything enqueued on the context's own stream has finished. */
 int tfhe_amd_ctx_synchronize(tfhe_amd_ctx* ctx);

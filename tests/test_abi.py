@@ -19,7 +19,8 @@ def declared_functions():
 
 def test_header_declares_the_expected_surface():
     names = declared_functions()
-    for must in ["tfhe_amd_ctx_create", "tfhe_amd_ctx_create_device", "tfhe_amd_ctx_destroy", "tfhe_amd_nand_batch",
+    for must in ["tfhe_amd_ctx_create", "tfhe_amd_blind_rotate_batch", "tfhe_amd_external_product_batch",
+                 "tfhe_amd_cmux_batch", "tfhe_amd_ctx_destroy", "tfhe_amd_nand_batch",
                  "tfhe_amd_nand_batch_device", "tfhe_amd_bootstrap_batch", "tfhe_amd_bootstrap_batch_device",
                  "tfhe_amd_gate_bootstrapping_batch_device", "tfhe_amd_identity_key_switch_batch_device"]:
         assert must in names
@@ -49,7 +50,7 @@ def test_argument_errors_without_gpu():
     lib = tfhe_amd.library()
     p = tfhe_amd.params_default()
     h = C.c_void_p()
-    assert lib.tfhe_amd_ctx_create(C.byref(p), None, None, 0, C.byref(h)) == 1
+    assert lib.tfhe_amd_ctx_create(C.byref(p), None, None, 0, 0, C.byref(h)) == 1
     assert b"null" in lib.tfhe_amd_last_error()
     assert lib.tfhe_amd_nand_batch(None, None, None, None, 4) == 1
     with pytest.raises(ValueError):

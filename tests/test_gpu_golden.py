@@ -1,0 +1,115 @@
+"""GPU path, called through the C ABI, against vectors produced by the REAL reference
+(tests/golden/*.npz): the parameter-generic exact kernels at toy ring degrees, where the
+reference itself is exact (reference src/types.hpp:225-236).  Bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+SETS = ["toyA", "toyB", "toyC"]
+
+
+def _params(arr):
+    import tfhe_amd
+
+    return tfhe_amd.Params(*[int(v) for v in arr])
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_external_product_and_cmux_vs_reference(golden, name):
+    # reference src/trgsw.hpp:100-117
+    import tfhe_amd
+
+    g = golden(name)
+    p = _params(g["params"])
+    assert np.array_equal(tfhe_amd.external_product(p, g["ep_trgsw"], g["ep_in"]), g["ep_out"])
+    assert np.array_equal(tfhe_amd.cmux(p, g["ep_trgsw"], g["cmux_d0"], g["cmux_d1"]), g["cmux_out"])
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_nand_pipeline_vs_reference(golden, name):
+    # reference src/hom_nand.hpp:74-81 and every stage below it
+    import tfhe_amd
+
+    g = golden(name)
+    p = _params(g["params"])
+    with tfhe_amd.Context(p, g["bk"], g["ks"]) as ctx:
+        assert np.array_equal(ctx.blind_rotate(g["c"]), g["acc"])
+        assert np.array_equal(ctx.gate_bootstrapping_tlwe_to_tlwe(g["c"]), g["lv1"])
+        assert np.array_equal(ctx.identity_key_switch(g["lv1"]), g["out"])
+        assert np.array_equal(ctx.bootstrap(g["c"]), g["out"])
+        assert np.array_equal(ctx.nand(g["a"], g["b"]), g["out"])
+
+
+@pytest.mark.parametrize("tag", ["t5", "t8", "t3b3"])
+def test_identity_key_switch_vs_reference(golden, tag):
+    # reference src/tlwe_key_switching.hpp:47-65; context with a key-switching key only
+    import tfhe_amd
+
+    g = golden("ks")
+    n, nlv1, _, _, _, T, bb = [int(v) for v in g[f"{tag}_params"]]
+    N = nlv1 & -nlv1  # the key switch only sees N*K = nlv1; pick a power-of-two N dividing it
+    p = tfhe_amd.Params(n, N, nlv1 // N, 8, 1, T, bb)
+    with tfhe_amd.Context(p, None, g[f"{tag}_ks"]) as ctx:
+        assert np.array_equal(ctx.identity_key_switch(g[f"{tag}_in"]), g[f"{tag}_out"])
+        with pytest.raises(tfhe_amd.TfheAmdError):
+            ctx.bootstrap(np.zeros((1, n + 1), np.uint32))  # no bootstrapping key in this context
+
+
+def test_blind_rotate_custom_test_vector_vs_reference(golden):
+    # reference src/trgsw.hpp:155-158 with n = 0 steps is only the initial rotation
+    import tfhe_amd
+
+    g = golden("rot512")
+    p = tfhe_amd.Params(1, 512, 2, 8, 2, 5, 2)
+    tv = np.zeros((3, 512), dtype=np.uint32)
+    tv[0] = np.arange(1, 513)
+    # one all-zero TRGSW row: CMUX with a zero selector leaves the accumulator unchanged
+    bk = np.zeros(p.bk_shape(), dtype=np.uint32)
+    c = np.zeros((len(g["b"]), 2), dtype=np.uint32)
+    c[:, 0] = g["b"]
+    c[:, 1] = np.arange(len(g["b"])) * 0x01234567
+    for generic in (False, True):
+        with tfhe_amd.Context(p, bk, None, generic_kernels=generic) as ctx:
+            acc = ctx.blind_rotate(c, tv)
+        assert np.array_equal(acc[:, 0, :], g["out"]), generic
+        assert not acc[:, 1:, :].any()
+
+
+def test_fast_and_generic_kernels_agree_at_default_parameters():
+    """The NTT kernels and the O(N^2) wrap-around kernels are independent implementations."""
+    import tfhe_amd
+
+    p = O.params_default()
+    rs = np.random.RandomState(9)
+    bk = rs.randint(0, 2**32, size=(24,) + p.bk_shape()[1:], dtype=np.uint64).astype(np.uint32)
+    p24 = tfhe_amd.Params(24, 512, 2, 8, 2, 5, 2)  # 24 blind-rotate steps keep the O(N^2) path short
+    c = rs.randint(0, 2**32, size=(6, 25), dtype=np.uint64).astype(np.uint32)
+    tv = rs.randint(0, 2**32, size=(3, 512), dtype=np.uint64).astype(np.uint32)
+    with tfhe_amd.Context(p24, bk, None) as fast, tfhe_amd.Context(p24, bk, None, generic_kernels=True) as gen:
+        for t in (None, tv):
+            assert np.array_equal(fast.blind_rotate(c, t), gen.blind_rotate(c, t))
+        assert np.array_equal(fast.gate_bootstrapping_tlwe_to_tlwe(c), gen.gate_bootstrapping_tlwe_to_tlwe(c))
+    # and the oracle agrees with both
+    op = O.params_from(24, 512, 2, 8, 2, 5, 2)
+    with tfhe_amd.Context(p24, bk, None) as fast:
+        got = fast.blind_rotate(c, tv)
+    for i in range(2):
+        assert np.array_equal(got[i], O.blind_rotate(c[i], bk, op, O.NTT, tv=tv))
+
+
+def test_external_product_default_size_vs_oracle_and_reference_fft(golden):
+    """N = 512: exact result equals the oracle; the reference's own floating-point product
+    (reference src/types.hpp:237-292) is the exact one minus at most 6 (documented relation)."""
+    import tfhe_amd
+
+    g = golden("extprod512")
+    p = tfhe_amd.params_default()
+    got = tfhe_amd.external_product(p, g["trgsw"], g["in"])
+    op = O.params_default()
+    for i in range(got.shape[0]):
+        assert np.array_equal(got[i], O.external_product(g["trgsw"][i], g["in"][i], op, O.NTT))
+    delta = (g["out"].astype(np.int64) - got.astype(np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)
+    assert delta.min() >= -6 and delta.max() <= 0

@@ -81,16 +81,21 @@ def library():
     lib.tfhe_amd_bk_words.restype = sz
     lib.tfhe_amd_ks_words.argtypes = [pp]
     lib.tfhe_amd_ks_words.restype = sz
-    lib.tfhe_amd_ctx_create.argtypes = [pp, vp, vp, i32, C.POINTER(vp)]
-    lib.tfhe_amd_ctx_create_device.argtypes = [pp, vp, vp, i32, C.POINTER(vp)]
+    lib.tfhe_amd_ctx_create.argtypes = [pp, vp, vp, i32, C.c_uint, C.POINTER(vp)]
     lib.tfhe_amd_ctx_destroy.argtypes = [vp]
     lib.tfhe_amd_ctx_destroy.restype = None
     lib.tfhe_amd_nand_batch.argtypes = [vp, vp, vp, vp, sz]
     lib.tfhe_amd_nand_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.tfhe_amd_bootstrap_batch.argtypes = [vp, vp, vp, sz]
     lib.tfhe_amd_bootstrap_batch_device.argtypes = [vp, vp, vp, sz, vp]
+    lib.tfhe_amd_gate_bootstrapping_batch.argtypes = [vp, vp, vp, sz]
     lib.tfhe_amd_gate_bootstrapping_batch_device.argtypes = [vp, vp, vp, sz, vp]
+    lib.tfhe_amd_blind_rotate_batch.argtypes = [vp, vp, vp, vp, sz]
+    lib.tfhe_amd_blind_rotate_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.tfhe_amd_identity_key_switch_batch.argtypes = [vp, vp, vp, sz]
     lib.tfhe_amd_identity_key_switch_batch_device.argtypes = [vp, vp, vp, sz, vp]
+    lib.tfhe_amd_external_product_batch.argtypes = [pp, vp, vp, vp, sz, i32]
+    lib.tfhe_amd_cmux_batch.argtypes = [pp, vp, vp, vp, vp, sz, i32]
     lib.tfhe_amd_ctx_synchronize.argtypes = [vp]
     lib.tfhe_amd_ctx_enable_timing.argtypes = [vp, i32]
     lib.tfhe_amd_ctx_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -133,23 +138,33 @@ class Context:
     """Device-resident evaluation key: what holding a HomNAND::EvaluateKey
     (reference src/hom_nand.hpp:36-42) becomes on the GPU."""
 
-    def __init__(self, params, bk, ks, device=0, keys_on_device=False):
+    KEYS_ON_DEVICE, GENERIC_KERNELS = 1, 2
+
+    def __init__(self, params, bk, ks, device=0, keys_on_device=False, generic_kernels=False):
+        """bk / ks: numpy uint32 arrays (host) or 32-bit torch GPU tensors (keys_on_device);
+        either may be None.  generic_kernels: use the parameter-generic exact O(N^2) kernels
+        even where a specialised NTT kernel exists."""
         lib = library()
         self.params = params
         self.device = int(device)
         self._h = C.c_void_p()
+        flags = (self.KEYS_ON_DEVICE if keys_on_device else 0) | (self.GENERIC_KERNELS if generic_kernels else 0)
+        bk_words, ks_words = lib.tfhe_amd_bk_words(C.byref(params)), lib.tfhe_amd_ks_words(C.byref(params))
         if keys_on_device:
-            rc = lib.tfhe_amd_ctx_create_device(C.byref(params), _dev_ptr(bk, lib.tfhe_amd_bk_words(C.byref(params))),
-                                                _dev_ptr(ks, lib.tfhe_amd_ks_words(C.byref(params))), self.device,
-                                                C.byref(self._h))
+            bk_p = _dev_ptr(bk, bk_words) if bk is not None else None
+            ks_p = _dev_ptr(ks, ks_words) if ks is not None else None
         else:
-            bk = _host_u32(bk).reshape(-1)
-            ks = _host_u32(ks).reshape(-1)
-            if bk.size != lib.tfhe_amd_bk_words(C.byref(params)) or ks.size != lib.tfhe_amd_ks_words(C.byref(params)):
-                raise ValueError("key sizes do not match the parameter set")
-            rc = lib.tfhe_amd_ctx_create(C.byref(params), bk.ctypes.data_as(C.c_void_p),
-                                         ks.ctypes.data_as(C.c_void_p), self.device, C.byref(self._h))
-        _check(rc)
+            keep = []
+            def host(x, words):
+                if x is None:
+                    return None
+                x = _host_u32(x).reshape(-1)
+                if x.size != words:
+                    raise ValueError("key sizes do not match the parameter set")
+                keep.append(x)
+                return x.ctypes.data_as(C.c_void_p)
+            bk_p, ks_p = host(bk, bk_words), host(ks, ks_words)
+        _check(lib.tfhe_amd_ctx_create(C.byref(params), bk_p, ks_p, self.device, flags, C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -187,6 +202,33 @@ class Context:
         out = np.empty_like(c)
         _check(library().tfhe_amd_bootstrap_batch(self._h, c.ctypes.data_as(C.c_void_p),
                                                   out.ctypes.data_as(C.c_void_p), c.shape[0]))
+        return out
+
+    def gate_bootstrapping_tlwe_to_tlwe(self, c):
+        """lv1[g] = sample_extract_index(blind_rotate(c[g]), 0) (reference src/trgsw.hpp:172-182)."""
+        c = _host_u32(c)
+        lv1 = np.empty((c.shape[0], self.params.lv1 + 1), dtype=np.uint32)
+        _check(library().tfhe_amd_gate_bootstrapping_batch(self._h, c.ctypes.data_as(C.c_void_p),
+                                                           lv1.ctypes.data_as(C.c_void_p), c.shape[0]))
+        return lv1
+
+    def blind_rotate(self, c, test_vector=None):
+        """acc[g] after the CMUX chain over c[g] (reference src/trgsw.hpp:131-170); test_vector
+        [K+1, N] or None for the gate-bootstrapping one."""
+        c = _host_u32(c)
+        tv = None if test_vector is None else _host_u32(test_vector, (self.params.K + 1, self.params.N))
+        acc = np.empty((c.shape[0], self.params.K + 1, self.params.N), dtype=np.uint32)
+        _check(library().tfhe_amd_blind_rotate_batch(self._h, c.ctypes.data_as(C.c_void_p),
+                                                     tv.ctypes.data_as(C.c_void_p) if tv is not None else None,
+                                                     acc.ctypes.data_as(C.c_void_p), c.shape[0]))
+        return acc
+
+    def identity_key_switch(self, lv1):
+        """out[g] = identity_key_switch(lv1[g]) (reference src/tlwe_key_switching.hpp:47-65)."""
+        lv1 = _host_u32(lv1)
+        out = np.empty((lv1.shape[0], self.params.n1), dtype=np.uint32)
+        _check(library().tfhe_amd_identity_key_switch_batch(self._h, lv1.ctypes.data_as(C.c_void_p),
+                                                            out.ctypes.data_as(C.c_void_p), lv1.shape[0]))
         return out
 
     # ---- GPU tensors (torch), asynchronous on `stream` (a torch stream or None) -------------
@@ -233,3 +275,23 @@ class Context:
         br, ks, n = C.c_double(), C.c_double(), C.c_int64()
         _check(library().tfhe_amd_ctx_timing(self._h, C.byref(br), C.byref(ks), C.byref(n)))
         return br.value, ks.value, n.value
+
+
+def external_product(params, trgsw, trlwe, device=0):
+    """out[b] = trgsw[b] (x) trlwe[b] (reference src/trgsw.hpp:100-110); host arrays."""
+    trgsw, trlwe = _host_u32(trgsw), _host_u32(trlwe)
+    out = np.empty_like(trlwe)
+    _check(library().tfhe_amd_external_product_batch(C.byref(params), trgsw.ctypes.data_as(C.c_void_p),
+                                                     trlwe.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                     trlwe.shape[0], int(device)))
+    return out
+
+
+def cmux(params, trgsw, d0, d1, device=0):
+    """out[b] = trgsw[b] (x) (d1[b] - d0[b]) + d0[b] (reference src/trgsw.hpp:112-117); host arrays."""
+    trgsw, d0, d1 = _host_u32(trgsw), _host_u32(d0), _host_u32(d1)
+    out = np.empty_like(d0)
+    _check(library().tfhe_amd_cmux_batch(C.byref(params), trgsw.ctypes.data_as(C.c_void_p),
+                                         d0.ctypes.data_as(C.c_void_p), d1.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), d0.shape[0], int(device)))
+    return out

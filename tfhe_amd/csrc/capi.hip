@@ -1,5 +1,6 @@
 // C ABI of the library (declared in include/tfhe_amd.h): context management, workspace,
-// stream handling and kernel timing around the launchers in kernels.hip.
+// stream handling and kernel timing around the launchers in kernels.hip and
+// generic_kernels.hip.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -23,12 +24,12 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(e_ == hipErrorOutOfMemory ? TFHE_AMD_ERR_MEMORY : TFHE_AMD_ERR_HIP,     \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+int hip_code(hipError_t e) { return e == hipErrorOutOfMemory ? TFHE_AMD_ERR_MEMORY : TFHE_AMD_ERR_HIP; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(hip_code(e_), std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
 struct DeviceGuard {
@@ -44,6 +45,14 @@ struct DeviceGuard {
     }
 };
 
+// device scratch buffer freed on scope exit
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
 constexpr int kTimingRing = 256;
 
 }  // namespace
@@ -51,10 +60,13 @@ constexpr int kTimingRing = 256;
 struct tfhe_amd_ctx {
     tfhe_amd_params p{};
     int device = 0;
+    bool fast = false;             // specialised NTT kernels (N = 512, K = 2, L = 2, 8-bit gadget)
     NttUniform u{};
     d2* d_tw = nullptr;
-    d2* d_bk_ntt = nullptr;
-    uint32_t* d_ks = nullptr;
+    d2* d_bk_ntt = nullptr;        // fast path
+    uint32_t* d_bk_raw = nullptr;  // generic path
+    uint32_t* d_ks = nullptr;      // packed
+    bool has_bk = false, has_ks = false;
     hipStream_t stream = nullptr;
     // workspace, grown on demand
     uint32_t* d_c = nullptr;
@@ -62,7 +74,7 @@ struct tfhe_amd_ctx {
     size_t ws_gates = 0;
     // staging for the host-pointer entry points
     uint32_t* d_io = nullptr;
-    size_t io_gates = 0;
+    size_t io_words = 0;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // kTimingRing * 3
@@ -82,10 +94,7 @@ bool params_sane(const tfhe_amd_params* p) {
     return true;
 }
 
-bool blind_rotate_supported(const tfhe_amd_params* p) {
-    return p->N == 512 && p->K == 2 && p->L == 2 && p->bg_bit == 8;
-}
-bool key_switch_supported(const tfhe_amd_params* p) { return key_switch_has_kernel(p->n + 1, p->T, p->base_bit); }
+bool fast_supported(const tfhe_amd_params* p) { return p->N == 512 && p->K == 2 && p->L == 2 && p->bg_bit == 8; }
 
 void build_uniform(NttUniform& u, const TwiddleSet& t) {
     u.p = (double)kP;
@@ -126,26 +135,29 @@ std::vector<double> build_tw_block_512(const TwiddleSet& t) {
     return blk;
 }
 
+size_t n1_of(const tfhe_amd_ctx* c) { return (size_t)c->p.n + 1; }
+size_t lv1_of(const tfhe_amd_ctx* c) { return (size_t)c->p.N * c->p.K + 1; }
+size_t trlwe_of(const tfhe_amd_ctx* c) { return (size_t)(c->p.K + 1) * c->p.N; }
+
 int ensure_workspace(tfhe_amd_ctx* ctx, size_t n_gates) {
     if (n_gates <= ctx->ws_gates) return TFHE_AMD_OK;
     if (ctx->d_c) (void)hipFree(ctx->d_c);
     if (ctx->d_lv1) (void)hipFree(ctx->d_lv1);
     ctx->d_c = ctx->d_lv1 = nullptr;
     ctx->ws_gates = 0;
-    const size_t n1 = (size_t)ctx->p.n + 1, l1 = (size_t)ctx->p.N * ctx->p.K + 1;
-    HIP_TRY(hipMalloc(&ctx->d_c, n_gates * n1 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&ctx->d_lv1, n_gates * l1 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_c, n_gates * n1_of(ctx) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&ctx->d_lv1, n_gates * lv1_of(ctx) * sizeof(uint32_t)));
     ctx->ws_gates = n_gates;
     return TFHE_AMD_OK;
 }
 
-int ensure_io(tfhe_amd_ctx* ctx, size_t n_gates) {
-    if (n_gates <= ctx->io_gates) return TFHE_AMD_OK;
+int ensure_io(tfhe_amd_ctx* ctx, size_t words) {
+    if (words <= ctx->io_words) return TFHE_AMD_OK;
     if (ctx->d_io) (void)hipFree(ctx->d_io);
     ctx->d_io = nullptr;
-    ctx->io_gates = 0;
-    HIP_TRY(hipMalloc(&ctx->d_io, 3 * n_gates * ((size_t)ctx->p.n + 1) * sizeof(uint32_t)));
-    ctx->io_gates = n_gates;
+    ctx->io_words = 0;
+    HIP_TRY(hipMalloc(&ctx->d_io, words * sizeof(uint32_t)));
+    ctx->io_words = words;
     return TFHE_AMD_OK;
 }
 
@@ -165,9 +177,41 @@ int drain_timing(tfhe_amd_ctx* ctx, int keep) {
     return TFHE_AMD_OK;
 }
 
-// bootstrap + key switch on device data; c may alias nothing else
-int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s) {
+int need_bk(const tfhe_amd_ctx* ctx) {
+    return ctx->has_bk ? TFHE_AMD_OK : fail(TFHE_AMD_ERR_ARGUMENT, "context holds no bootstrapping key");
+}
+int need_ks(const tfhe_amd_ctx* ctx) {
+    return ctx->has_ks ? TFHE_AMD_OK : fail(TFHE_AMD_ERR_ARGUMENT, "context holds no key-switching key");
+}
+
+int check_batch(const tfhe_amd_ctx* ctx, size_t n_gates, bool ptrs_ok) {
+    if (!ctx) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
+    if (n_gates && !ptrs_ok) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
+    if (n_gates > (size_t)1 << 30) return fail(TFHE_AMD_ERR_ARGUMENT, "batch too large");
+    return TFHE_AMD_OK;
+}
+
+// blind rotation of device data: extract != 0 -> lv1 layout, else accumulators
+int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, uint32_t* out, size_t n_gates,
+                     int extract, hipStream_t s) {
     const tfhe_amd_params& p = ctx->p;
+    if (ctx->fast)
+        HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)n_gates, p.n, p.K, p.L,
+                                        extract, s));
+    else
+        HIP_TRY(launch_blind_rotate_generic(ctx->d_bk_raw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit, extract,
+                                            s));
+    return TFHE_AMD_OK;
+}
+
+int run_key_switch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t n_gates, hipStream_t s) {
+    const tfhe_amd_params& p = ctx->p;
+    HIP_TRY(launch_key_switch(lv1, ctx->d_ks, out, (int)n_gates, p.n + 1, p.N * p.K, p.T, p.base_bit, s));
+    return TFHE_AMD_OK;
+}
+
+// bootstrap + key switch on device data, with optional event timing
+int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s) {
     hipEvent_t* e = nullptr;
     if (ctx->timing) {
         if (ctx->ev_count == kTimingRing) {
@@ -177,9 +221,11 @@ int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_
         e = &ctx->ev[(size_t)((ctx->ev_head + ctx->ev_count) % kTimingRing) * 3];
         HIP_TRY(hipEventRecord(e[0], s));
     }
-    HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, ctx->d_lv1, (int)n_gates, p.n, p.K, p.L, s));
+    int rc = run_blind_rotate(ctx, c, nullptr, ctx->d_lv1, n_gates, 1, s);
+    if (rc) return rc;
     if (e) HIP_TRY(hipEventRecord(e[1], s));
-    HIP_TRY(launch_key_switch(ctx->d_lv1, ctx->d_ks, out, (int)n_gates, p.n + 1, p.N * p.K, p.T, p.base_bit, s));
+    rc = run_key_switch(ctx, ctx->d_lv1, out, n_gates, s);
+    if (rc) return rc;
     if (e) {
         HIP_TRY(hipEventRecord(e[2], s));
         ctx->ev_count++;
@@ -187,69 +233,55 @@ int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_
     return TFHE_AMD_OK;
 }
 
-int create_common(const tfhe_amd_params* p, const uint32_t* bk, const uint32_t* ks, bool on_device, int device,
-                  tfhe_amd_ctx** out) {
-    if (!out) return fail(TFHE_AMD_ERR_ARGUMENT, "out is null");
-    *out = nullptr;
-    if (!params_sane(p) || !bk || !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "bad parameters or null key pointer");
-    int rc = tfhe_amd_params_supported(p);
+// Host-pointer wrapper: copies `n_in` input arrays to the staging buffer, runs `body` on the
+// device copies, copies one output array back.  in_words[k] / out_words are per-array sizes.
+template <typename Body>
+int with_staging(tfhe_amd_ctx* ctx, const uint32_t* const* in, const size_t* in_words, int n_in, uint32_t* out,
+                 size_t out_words, Body body) {
+    size_t total = out_words;
+    for (int k = 0; k < n_in; k++) total += in_words[k];
+    int rc = ensure_io(ctx, total);
     if (rc) return rc;
+    const uint32_t* dev_in[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* cur = ctx->d_io;
+    for (int k = 0; k < n_in; k++) {
+        if (in[k]) {
+            HIP_TRY(hipMemcpyAsync(cur, in[k], in_words[k] * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            dev_in[k] = cur;
+        }
+        cur += in_words[k];
+    }
+    rc = body(dev_in, cur);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, cur, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return TFHE_AMD_OK;
+}
+
+int external_product_common(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
+                            uint32_t* out, size_t batch, int device, int mode) {
+    if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
+    if (!generic_has_kernel(p->N, p->K, p->L))
+        return fail(TFHE_AMD_ERR_UNSUPPORTED, "ring too large for the generic kernel");
+    if (batch && (!trgsw || !x0 || !out || (mode && !x1))) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
+    if (batch == 0) return TFHE_AMD_OK;
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
-
-    tfhe_amd_ctx* ctx = new (std::nothrow) tfhe_amd_ctx();
-    if (!ctx) return fail(TFHE_AMD_ERR_MEMORY, "host allocation failed");
-    ctx->p = *p;
-    ctx->device = device;
-    auto bail = [&](int code) {
-        tfhe_amd_ctx_destroy(ctx);
-        return code;
-    };
-#define CTX_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return bail(fail(e_ == hipErrorOutOfMemory ? TFHE_AMD_ERR_MEMORY : TFHE_AMD_ERR_HIP,    \
-                             std::string(#expr) + ": " + hipGetErrorString(e_)));                  \
-    } while (0)
-
-    CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    const TwiddleSet tw = make_twiddles(p->N);
-    build_uniform(ctx->u, tw);
-    const std::vector<double> blk = build_tw_block_512(tw);
-    CTX_TRY(hipMalloc(&ctx->d_tw, blk.size() * sizeof(double)));
-    CTX_TRY(hipMemcpyAsync(ctx->d_tw, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-
-    const size_t bk_words = tfhe_amd_bk_words(p), ks_words = tfhe_amd_ks_words(p);
-    const int n1 = p->n + 1, nlv1 = p->N * p->K;
-    CTX_TRY(hipMalloc(&ctx->d_bk_ntt, bk_words * sizeof(double)));
-    CTX_TRY(hipMalloc(&ctx->d_ks, key_switch_packed_words(n1, nlv1, p->T, p->base_bit) * sizeof(uint32_t)));
-    // raw keys: uploaded to scratch buffers (host source) or used in place (device source)
-    uint32_t *d_bk_raw = nullptr, *d_ks_raw = nullptr;
-    const uint32_t *bk_src = bk, *ks_src = ks;
-    hipError_t e2 = hipSuccess;
-    if (!on_device) {
-        e2 = hipMalloc(&d_bk_raw, bk_words * sizeof(uint32_t));
-        if (e2 == hipSuccess) e2 = hipMalloc(&d_ks_raw, ks_words * sizeof(uint32_t));
-        if (e2 == hipSuccess)
-            e2 = hipMemcpyAsync(d_bk_raw, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e2 == hipSuccess)
-            e2 = hipMemcpyAsync(d_ks_raw, ks, ks_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-        bk_src = d_bk_raw;
-        ks_src = d_ks_raw;
-    }
-    if (e2 == hipSuccess)
-        e2 = launch_bk_transform_512(ctx->u, ctx->d_tw, bk_src, ctx->d_bk_ntt, (int)(bk_words / p->N), ctx->stream);
-    if (e2 == hipSuccess) e2 = launch_ks_pack(ctx->d_ks, ks_src, n1, nlv1, p->T, p->base_bit, ctx->stream);
-    if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
-    if (d_bk_raw) (void)hipFree(d_bk_raw);
-    if (d_ks_raw) (void)hipFree(d_ks_raw);
-    CTX_TRY(e2);
-#undef CTX_TRY
-    *out = ctx;
+    const size_t W = (size_t)(p->K + 1) * p->N, GW = W * (p->K + 1) * p->L;
+    DevBuf dg, d0, d1, dout;
+    HIP_TRY(dg.alloc(batch * GW * 4));
+    HIP_TRY(d0.alloc(batch * W * 4));
+    HIP_TRY(d1.alloc(batch * W * 4));
+    HIP_TRY(dout.alloc(batch * W * 4));
+    HIP_TRY(hipMemcpy(dg.p, trgsw, batch * GW * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d0.p, x0, batch * W * 4, hipMemcpyHostToDevice));
+    if (mode) HIP_TRY(hipMemcpy(d1.p, x1, batch * W * 4, hipMemcpyHostToDevice));
+    HIP_TRY(launch_external_product_generic(dg.as<uint32_t>(), d0.as<uint32_t>(), d1.as<uint32_t>(),
+                                            dout.as<uint32_t>(), batch, p->N, p->K, p->L, p->bg_bit, mode, nullptr));
+    HIP_TRY(hipMemcpy(out, dout.p, batch * W * 4, hipMemcpyDeviceToHost));
     return TFHE_AMD_OK;
 }
 
@@ -264,8 +296,10 @@ void tfhe_amd_params_default(tfhe_amd_params* p) {
 
 int tfhe_amd_params_supported(const tfhe_amd_params* p) {
     if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
-    if (!blind_rotate_supported(p)) return fail(TFHE_AMD_ERR_UNSUPPORTED, "no blind-rotation kernel for this ring/gadget");
-    if (!key_switch_supported(p)) return fail(TFHE_AMD_ERR_UNSUPPORTED, "no key-switch kernel for this base/size");
+    if (!fast_supported(p) && !generic_has_kernel(p->N, p->K, p->L))
+        return fail(TFHE_AMD_ERR_UNSUPPORTED, "no blind-rotation kernel for this ring/gadget");
+    if (!key_switch_has_kernel(p->n + 1, p->T, p->base_bit))
+        return fail(TFHE_AMD_ERR_UNSUPPORTED, "no key-switch kernel for this base/size");
     return TFHE_AMD_OK;
 }
 
@@ -276,50 +310,109 @@ size_t tfhe_amd_ks_words(const tfhe_amd_params* p) {
     return (size_t)p->N * p->K * p->T * ((size_t)1 << p->base_bit) * (p->n + 1);
 }
 
-int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk_host, const uint32_t* ks_host, int device,
+int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint32_t* ks, int device, unsigned flags,
                         tfhe_amd_ctx** out) {
-    return create_common(p, bk_host, ks_host, false, device, out);
-}
+    if (!out) return fail(TFHE_AMD_ERR_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
+    if (!bk && !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "both key pointers are null");
+    int rc = tfhe_amd_params_supported(p);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
+    const bool on_device = (flags & TFHE_AMD_CTX_KEYS_ON_DEVICE) != 0;
 
-int tfhe_amd_ctx_create_device(const tfhe_amd_params* p, const uint32_t* bk_dev, const uint32_t* ks_dev, int device,
-                               tfhe_amd_ctx** out) {
-    return create_common(p, bk_dev, ks_dev, true, device, out);
+    tfhe_amd_ctx* ctx = new (std::nothrow) tfhe_amd_ctx();
+    if (!ctx) return fail(TFHE_AMD_ERR_MEMORY, "host allocation failed");
+    ctx->p = *p;
+    ctx->device = device;
+    ctx->fast = fast_supported(p) && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
+    auto bail = [&](hipError_t e, const char* what) {
+        tfhe_amd_ctx_destroy(ctx);
+        return fail(hip_code(e), std::string(what) + ": " + hipGetErrorString(e));
+    };
+#define CTX_TRY(expr)                                     \
+    do {                                                  \
+        hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) return bail(e_, #expr);     \
+    } while (0)
+
+    CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const size_t bk_words = tfhe_amd_bk_words(p), ks_words = tfhe_amd_ks_words(p);
+    const int n1 = p->n + 1, nlv1 = p->N * p->K;
+    DevBuf up_bk, up_ks;  // upload scratch for host-resident keys
+    if (bk) {
+        const uint32_t* src = bk;
+        if (ctx->fast) {
+            const TwiddleSet tw = make_twiddles(p->N);
+            build_uniform(ctx->u, tw);
+            const std::vector<double> blk = build_tw_block_512(tw);
+            CTX_TRY(hipMalloc(&ctx->d_tw, blk.size() * sizeof(double)));
+            CTX_TRY(hipMemcpy(ctx->d_tw, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));
+            CTX_TRY(hipMalloc(&ctx->d_bk_ntt, bk_words * sizeof(double)));
+            if (!on_device) {
+                CTX_TRY(up_bk.alloc(bk_words * sizeof(uint32_t)));
+                CTX_TRY(hipMemcpyAsync(up_bk.p, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                src = up_bk.as<uint32_t>();
+            }
+            CTX_TRY(launch_bk_transform_512(ctx->u, ctx->d_tw, src, ctx->d_bk_ntt, (int)(bk_words / p->N), ctx->stream));
+        } else {
+            CTX_TRY(hipMalloc(&ctx->d_bk_raw, bk_words * sizeof(uint32_t)));
+            CTX_TRY(hipMemcpyAsync(ctx->d_bk_raw, bk, bk_words * sizeof(uint32_t),
+                                   on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        }
+        ctx->has_bk = true;
+    }
+    if (ks) {
+        const uint32_t* src = ks;
+        CTX_TRY(hipMalloc(&ctx->d_ks, key_switch_packed_words(n1, nlv1, p->T, p->base_bit) * sizeof(uint32_t)));
+        if (!on_device) {
+            CTX_TRY(up_ks.alloc(ks_words * sizeof(uint32_t)));
+            CTX_TRY(hipMemcpyAsync(up_ks.p, ks, ks_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            src = up_ks.as<uint32_t>();
+        }
+        CTX_TRY(launch_ks_pack(ctx->d_ks, src, n1, nlv1, p->T, p->base_bit, ctx->stream));
+        ctx->has_ks = true;
+    }
+    CTX_TRY(hipStreamSynchronize(ctx->stream));
+#undef CTX_TRY
+    *out = ctx;
+    return TFHE_AMD_OK;
 }
 
 void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
-    if (ctx->d_tw) (void)hipFree(ctx->d_tw);
-    if (ctx->d_bk_ntt) (void)hipFree(ctx->d_bk_ntt);
-    if (ctx->d_ks) (void)hipFree(ctx->d_ks);
-    if (ctx->d_c) (void)hipFree(ctx->d_c);
-    if (ctx->d_lv1) (void)hipFree(ctx->d_lv1);
-    if (ctx->d_io) (void)hipFree(ctx->d_io);
+    for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    void* bufs[] = {ctx->d_tw, ctx->d_bk_ntt, ctx->d_bk_raw, ctx->d_ks, ctx->d_c, ctx->d_lv1, ctx->d_io};
+    for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
+// ---- device-pointer entry points -----------------------------------------------------------
+
 int tfhe_amd_bootstrap_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates,
                                     void* stream) {
-    if (!ctx || (n_gates && (!c || !out))) return fail(TFHE_AMD_ERR_ARGUMENT, "null argument");
-    if (n_gates == 0) return TFHE_AMD_OK;
-    if (n_gates > (size_t)1 << 30) return fail(TFHE_AMD_ERR_ARGUMENT, "batch too large");
+    int rc = check_batch(ctx, n_gates, c && out);
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    int rc = ensure_workspace(ctx, n_gates);
-    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
     return run_bootstrap(ctx, c, out, n_gates, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
                                size_t n_gates, void* stream) {
-    if (!ctx || (n_gates && (!a || !b || !out))) return fail(TFHE_AMD_ERR_ARGUMENT, "null argument");
-    if (n_gates == 0) return TFHE_AMD_OK;
-    if (n_gates > (size_t)1 << 30) return fail(TFHE_AMD_ERR_ARGUMENT, "batch too large");
+    int rc = check_batch(ctx, n_gates, a && b && out);
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    int rc = ensure_workspace(ctx, n_gates);
-    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     HIP_TRY(launch_nand_combine(ctx->d_c, a, b, n_gates, ctx->p.n + 1, s));
     return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
@@ -327,58 +420,102 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
 
 int tfhe_amd_gate_bootstrapping_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* lv1, size_t n_gates,
                                              void* stream) {
-    if (!ctx || (n_gates && (!c || !lv1))) return fail(TFHE_AMD_ERR_ARGUMENT, "null argument");
-    if (n_gates == 0) return TFHE_AMD_OK;
+    int rc = check_batch(ctx, n_gates, c && lv1);
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    const tfhe_amd_params& p = ctx->p;
-    HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, lv1, (int)n_gates, p.n, p.K, p.L,
-                                    stream ? (hipStream_t)stream : ctx->stream));
-    return TFHE_AMD_OK;
+    return run_blind_rotate(ctx, c, nullptr, lv1, n_gates, 1, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+int tfhe_amd_blind_rotate_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* test_vector,
+                                       uint32_t* acc, size_t n_gates, void* stream) {
+    int rc = check_batch(ctx, n_gates, c && acc);
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx))) return rc;
+    DeviceGuard guard(ctx->device);
+    return run_blind_rotate(ctx, c, test_vector, acc, n_gates, 0, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int tfhe_amd_identity_key_switch_batch_device(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out,
                                               size_t n_gates, void* stream) {
-    if (!ctx || (n_gates && (!lv1 || !out))) return fail(TFHE_AMD_ERR_ARGUMENT, "null argument");
-    if (n_gates == 0) return TFHE_AMD_OK;
+    int rc = check_batch(ctx, n_gates, lv1 && out);
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    const tfhe_amd_params& p = ctx->p;
-    HIP_TRY(launch_key_switch(lv1, ctx->d_ks, out, (int)n_gates, p.n + 1, p.N * p.K, p.T, p.base_bit,
-                              stream ? (hipStream_t)stream : ctx->stream));
-    return TFHE_AMD_OK;
+    return run_key_switch(ctx, lv1, out, n_gates, stream ? (hipStream_t)stream : ctx->stream);
 }
 
+// ---- host-pointer entry points --------------------------------------------------------------
+
 int tfhe_amd_nand_batch(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n_gates) {
-    if (!ctx || (n_gates && (!a || !b || !out))) return fail(TFHE_AMD_ERR_ARGUMENT, "null argument");
-    if (n_gates == 0) return TFHE_AMD_OK;
+    int rc = check_batch(ctx, n_gates, a && b && out);
+    if (rc || n_gates == 0) return rc;
     DeviceGuard guard(ctx->device);
-    int rc = ensure_io(ctx, n_gates);
-    if (rc) return rc;
-    const size_t words = n_gates * ((size_t)ctx->p.n + 1), bytes = words * sizeof(uint32_t);
-    uint32_t *da = ctx->d_io, *db = ctx->d_io + words, *dout = ctx->d_io + 2 * words;
-    HIP_TRY(hipMemcpyAsync(da, a, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(db, b, bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = tfhe_amd_nand_batch_device(ctx, da, db, dout, n_gates, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return TFHE_AMD_OK;
+    const size_t w = n_gates * n1_of(ctx);
+    const uint32_t* in[2] = {a, b};
+    const size_t iw[2] = {w, w};
+    return with_staging(ctx, in, iw, 2, out, w, [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_nand_batch_device(ctx, d[0], d[1], o, n_gates, nullptr);
+    });
 }
 
 int tfhe_amd_bootstrap_batch(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates) {
-    if (!ctx || (n_gates && (!c || !out))) return fail(TFHE_AMD_ERR_ARGUMENT, "null argument");
-    if (n_gates == 0) return TFHE_AMD_OK;
+    int rc = check_batch(ctx, n_gates, c && out);
+    if (rc || n_gates == 0) return rc;
     DeviceGuard guard(ctx->device);
-    int rc = ensure_io(ctx, n_gates);
-    if (rc) return rc;
-    const size_t words = n_gates * ((size_t)ctx->p.n + 1), bytes = words * sizeof(uint32_t);
-    uint32_t *dc = ctx->d_io, *dout = ctx->d_io + 2 * words;
-    HIP_TRY(hipMemcpyAsync(dc, c, bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = tfhe_amd_bootstrap_batch_device(ctx, dc, dout, n_gates, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return TFHE_AMD_OK;
+    const size_t w = n_gates * n1_of(ctx);
+    const uint32_t* in[1] = {c};
+    const size_t iw[1] = {w};
+    return with_staging(ctx, in, iw, 1, out, w, [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_bootstrap_batch_device(ctx, d[0], o, n_gates, nullptr);
+    });
 }
+
+int tfhe_amd_gate_bootstrapping_batch(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* lv1, size_t n_gates) {
+    int rc = check_batch(ctx, n_gates, c && lv1);
+    if (rc || n_gates == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    const uint32_t* in[1] = {c};
+    const size_t iw[1] = {n_gates * n1_of(ctx)};
+    return with_staging(ctx, in, iw, 1, lv1, n_gates * lv1_of(ctx), [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_gate_bootstrapping_batch_device(ctx, d[0], o, n_gates, nullptr);
+    });
+}
+
+int tfhe_amd_blind_rotate_batch(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* test_vector, uint32_t* acc,
+                                size_t n_gates) {
+    int rc = check_batch(ctx, n_gates, c && acc);
+    if (rc || n_gates == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    const uint32_t* in[2] = {c, test_vector};
+    const size_t iw[2] = {n_gates * n1_of(ctx), trlwe_of(ctx)};
+    return with_staging(ctx, in, iw, 2, acc, n_gates * trlwe_of(ctx), [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_blind_rotate_batch_device(ctx, d[0], d[1], o, n_gates, nullptr);
+    });
+}
+
+int tfhe_amd_identity_key_switch_batch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t n_gates) {
+    int rc = check_batch(ctx, n_gates, lv1 && out);
+    if (rc || n_gates == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    const uint32_t* in[1] = {lv1};
+    const size_t iw[1] = {n_gates * lv1_of(ctx)};
+    return with_staging(ctx, in, iw, 1, out, n_gates * n1_of(ctx), [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_identity_key_switch_batch_device(ctx, d[0], o, n_gates, nullptr);
+    });
+}
+
+int tfhe_amd_external_product_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* trlwe,
+                                    uint32_t* out, size_t batch, int device) {
+    return external_product_common(p, trgsw, trlwe, nullptr, out, batch, device, 0);
+}
+
+int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* d0, const uint32_t* d1,
+                        uint32_t* out, size_t batch, int device) {
+    return external_product_common(p, trgsw, d0, d1, out, batch, device, 1);
+}
+
+// ---- housekeeping ----------------------------------------------------------------------------
 
 int tfhe_amd_ctx_synchronize(tfhe_amd_ctx* ctx) {
     if (!ctx) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
@@ -391,11 +528,8 @@ int tfhe_amd_ctx_enable_timing(tfhe_amd_ctx* ctx, int enable) {
     if (!ctx) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
     DeviceGuard guard(ctx->device);
     if (enable && ctx->ev.empty()) {
-        ctx->ev.resize((size_t)kTimingRing * 3);
-        for (hipEvent_t& e : ctx->ev) {
-            e = nullptr;
-            HIP_TRY(hipEventCreate(&e));
-        }
+        ctx->ev.assign((size_t)kTimingRing * 3, nullptr);
+        for (hipEvent_t& e : ctx->ev) HIP_TRY(hipEventCreate(&e));
     }
     if (!enable) {
         int rc = drain_timing(ctx, 0);
@@ -419,6 +553,6 @@ int tfhe_amd_ctx_timing(tfhe_amd_ctx* ctx, double* blind_rotate_ms, double* key_
 }
 
 const char* tfhe_amd_last_error(void) { return g_last_error.c_str(); }
-const char* tfhe_amd_version(void) { return "0.1.0"; }
+const char* tfhe_amd_version(void) { return "0.2.0"; }
 
 }  // extern "C"

@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(256) bk_transform_512_kernel(const NttUniform 
 template <int K, int L>
 __global__ void __launch_bounds__(256, 2)
 blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2* __restrict__ bk_ntt,
-                        const uint32_t* __restrict__ c, uint32_t* __restrict__ lv1, int n_gates, int n) {
+                        const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv, uint32_t* __restrict__ out,
+                        int n_gates, int n, int extract) {
     constexpr int K1 = K + 1, R = K1 * L, BG = 8;
     __shared__ d2 s_tw[kTwPairs];
     __shared__ double s_tr[4][kTrPad];
@@ -91,16 +92,19 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
     const uint32_t* cg = c + (size_t)gate * (n + 1);
     const double p = u.p, pinv = u.pinv;
 
-    // acc = testvector * X^(-floor(b * 2N)); test vector = (1/8, .., 1/8 | 0 | 0)
+    // acc = testvector * X^(-floor(b * 2N)); tv == nullptr: the gate-bootstrapping test vector
+    // (1/8, .., 1/8 | 0 | 0) of reference src/trgsw.hpp:177-179
     {
         const int bbar = (int)(cg[0] >> 22);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int j = 64 * k + lane;
             const int s = (j + bbar) & (2 * kN - 1);
-            acc[0][j] = (s & kN) ? 0u - (1u << 29) : (1u << 29);
 #pragma unroll
-            for (int q = 1; q < K1; q++) acc[q][j] = 0u;
+            for (int q = 0; q < K1; q++) {
+                const uint32_t v = tv ? tv[q * kN + (s & (kN - 1))] : (q == 0 ? (1u << 29) : 0u);
+                acc[q][j] = (s & kN) ? 0u - v : v;
+            }
         }
     }
     wave_lds_fence();
@@ -159,9 +163,17 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
         wave_lds_fence();
     }
 
+    if (!extract) {  // raw accumulator [K1][N]
+        uint32_t* o = out + (size_t)gate * (K1 * kN);
+#pragma unroll
+        for (int q = 0; q < K1; q++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[q * kN + 64 * k + lane] = acc[q][64 * k + lane];
+        return;
+    }
     // sample extraction at index 0 (reference src/trlwe.hpp:109-122):
     // lv1[0] = b[0]; lv1[1 + q N] = a_q[0]; lv1[1 + q N + i] = -a_q[N - i]
-    uint32_t* o = lv1 + (size_t)gate * (K * kN + 1);
+    uint32_t* o = out + (size_t)gate * (K * kN + 1);
     if (lane == 0) o[0] = acc[0][0];
 #pragma unroll
     for (int q = 0; q < K; q++)
@@ -366,11 +378,12 @@ hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint
 }
 
 hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
-                                   uint32_t* lv1, int n_gates, int n, int K, int L, hipStream_t stream) {
+                                   const uint32_t* tv, uint32_t* out, int n_gates, int n, int K, int L, int extract,
+                                   hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n_gates + 3) / 4);
     if (K == 2 && L == 2)
-        blind_rotate_512_kernel<2, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, lv1, n_gates, n);
+        blind_rotate_512_kernel<2, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, tv, out, n_gates, n, extract);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -13,8 +13,19 @@ hipError_t launch_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b
                                hipStream_t stream);
 hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint32_t* bk, d2* bk_ntt, int n_polys,
                                    hipStream_t stream);
+// tv: test vector [K+1][N] shared by all gates or nullptr (gate bootstrapping); extract != 0
+// writes sample_extract_index(acc, 0), else the accumulator
 hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
-                                   uint32_t* lv1, int n_gates, int n, int K, int L, hipStream_t stream);
+                                   const uint32_t* tv, uint32_t* out, int n_gates, int n, int K, int L, int extract,
+                                   hipStream_t stream);
+// exact O(N^2) kernels for any parameter set (generic_kernels.hip)
+bool generic_has_kernel(int N, int K, int L);
+hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
+                                           uint32_t* out, size_t batch, int N, int K, int L, int bg, int mode,
+                                           hipStream_t stream);
+hipError_t launch_blind_rotate_generic(const uint32_t* bk, const uint32_t* c, const uint32_t* tv, uint32_t* out,
+                                       size_t n_gates, int n, int N, int K, int L, int bg, int extract,
+                                       hipStream_t stream);
 bool key_switch_has_kernel(int n1, int T, int bb);
 // the key-switching key is kept on the device without its digit-0 rows, rows padded to
 // key_switch_row_words(n1) words
