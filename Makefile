@@ -6,19 +6,25 @@ HIPFLAGS ?= -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall
 SRC := tfhe_amd/csrc/kernels.hip tfhe_amd/csrc/generic_kernels.hip tfhe_amd/csrc/capi.hip
 HDR := tfhe_amd/csrc/kernels.hpp tfhe_amd/csrc/ntt512.hpp tfhe_amd/csrc/field.hpp include/tfhe_amd.h
 
-all: tfhe_amd/libtfhe_amd.so oracle
+all: tfhe_amd/libtfhe_amd.so oracle tests/cpp/dropin_test
 
 tfhe_amd/libtfhe_amd.so: $(SRC) $(HDR)
 	$(HIPCC) $(HIPFLAGS) -shared $(SRC) -o $@
 
+# behavioural tests of the drop-in headers (src/*.hpp) on top of the library
+DROPIN_HDR := $(wildcard src/*.hpp)
+tests/cpp/dropin_test: tests/cpp/test_dropin.cpp tests/cpp/test_dropin_tu2.cpp $(DROPIN_HDR) tfhe_amd/libtfhe_amd.so
+	g++ -std=gnu++17 -O2 -Wall -I src -I include tests/cpp/test_dropin.cpp tests/cpp/test_dropin_tu2.cpp -o $@ \
+	    -L tfhe_amd -ltfhe_amd -Wl,-rpath,'$$ORIGIN/../../tfhe_amd'
+
 oracle:
 	$(MAKE) -C oracle liboracle.so
 
-ref:
+ref: tfhe_amd/libtfhe_amd.so
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f tfhe_amd/libtfhe_amd.so
+	rm -f tfhe_amd/libtfhe_amd.so tests/cpp/dropin_test
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle ref clean

@@ -1,0 +1,160 @@
+// Glue between the drop-in template headers and the C ABI of libtfhe_amd (include/tfhe_amd.h):
+// flattening of the reference's pointer-tree containers into the flat uint32_t layouts the
+// library takes, and a small cache of device contexts keyed on the identity of the key
+// objects (the reference's nand(a, b, evaluate_key) carries no context handle).
+//
+// Evaluation has no host implementation behind these calls: a missing library is a link
+// error, and every run-time failure throws std::runtime_error with the library's message.
+#pragma once
+
+#include <cstdint>
+#include <list>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tfhe_amd.h"
+#include "types.hpp"
+
+namespace TFHE {
+namespace gpu {
+
+inline void check(int rc, const char* what) {
+    if (rc != TFHE_AMD_OK)
+        throw std::runtime_error(std::string(what) + ": tfhe_amd error " + std::to_string(rc) + ": " +
+                                 tfhe_amd_last_error());
+}
+
+inline int& device() {  // GPU used by the header-level calls; change before the first evaluation
+    static int dev = 0;
+    return dev;
+}
+
+// ---- flatten / unflatten -------------------------------------------------------------------
+template <int N>
+void put(std::vector<uint32_t>& out, const Vector<TorusValue, N>& v) {
+    for (int i = 0; i < N; i++) out.push_back(v[i].get_raw_value());
+}
+template <int N>
+void put(std::vector<uint32_t>& out, const Polynomial<TorusValue, N>& v) {
+    for (int i = 0; i < N; i++) out.push_back(v[i].get_raw_value());
+}
+template <int N, int K1>
+void put(std::vector<uint32_t>& out, const Vector<Polynomial<TorusValue, N>, K1>& v) {
+    for (int q = 0; q < K1; q++) put(out, v[q]);
+}
+template <int N, int R, int K1>
+void put(std::vector<uint32_t>& out, const Matrix<Polynomial<TorusValue, N>, R, K1>& m) {
+    for (int r = 0; r < R; r++) put(out, m[r]);
+}
+// bootstrapping key: [n][(K+1)L][K+1][N]
+template <int N, int R, int K1, int TLWE_N>
+std::vector<uint32_t> flatten_bk(const Vector<Matrix<Polynomial<TorusValue, N>, R, K1>, TLWE_N>& bk) {
+    std::vector<uint32_t> out;
+    out.reserve((size_t)TLWE_N * R * K1 * N);
+    for (int i = 0; i < TLWE_N; i++) put(out, bk[i]);
+    return out;
+}
+// key-switching key: [N_LV1][T][2^BASE_BIT][N_LV0 + 1]
+template <int W, int B, int T, int N_LV1>
+std::vector<uint32_t> flatten_ks(const Vector<Vector<Vector<Vector<TorusValue, W>, B>, T>, N_LV1>& ks) {
+    std::vector<uint32_t> out;
+    out.reserve((size_t)N_LV1 * T * B * W);
+    for (int i = 0; i < N_LV1; i++)
+        for (int m = 0; m < T; m++)
+            for (int o = 0; o < B; o++) put(out, ks[i][m][o]);
+    return out;
+}
+template <int N>
+Vector<TorusValue, N> take_vector(const uint32_t* src) {
+    Vector<TorusValue, N> v;
+    for (int i = 0; i < N; i++) v[i] = TorusValue::from_raw_value(src[i]);
+    return v;
+}
+template <int N, int K1>
+Vector<Polynomial<TorusValue, N>, K1> take_trlwe(const uint32_t* src) {
+    Vector<Polynomial<TorusValue, N>, K1> v;
+    for (int q = 0; q < K1; q++)
+        for (int j = 0; j < N; j++) v[q][j] = TorusValue::from_raw_value(src[q * N + j]);
+    return v;
+}
+
+// ---- context cache ---------------------------------------------------------------------------
+// Keyed on the addresses of the caller's key objects plus a fingerprint of their contents, so a
+// key that is destroyed and another built at the same address is detected.
+class ContextCache {
+    struct Entry {
+        const void* bk_id;
+        const void* ks_id;
+        uint64_t print;
+        tfhe_amd_params params;
+        tfhe_amd_ctx* ctx;
+    };
+    std::list<Entry> entries_;
+    static constexpr size_t kMaxEntries = 4;
+
+    static bool same(const tfhe_amd_params& a, const tfhe_amd_params& b) {
+        return a.n == b.n && a.N == b.N && a.K == b.K && a.bg_bit == b.bg_bit && a.L == b.L && a.T == b.T &&
+               a.base_bit == b.base_bit;
+    }
+
+public:
+    ~ContextCache() { clear(); }
+    void clear() {
+        for (auto& e : entries_) tfhe_amd_ctx_destroy(e.ctx);
+        entries_.clear();
+    }
+
+    // `print`: cheap fingerprint of the key contents; `make_bk` / `make_ks`: produce the flat keys
+    // (an empty vector = that key is absent); only called on a miss.
+    template <typename MakeBk, typename MakeKs>
+    tfhe_amd_ctx* get(const tfhe_amd_params& params, const void* bk_id, const void* ks_id, uint64_t print,
+                      MakeBk make_bk, MakeKs make_ks) {
+        for (auto it = entries_.begin(); it != entries_.end(); ++it)
+            if (it->bk_id == bk_id && it->ks_id == ks_id && same(it->params, params)) {
+                if (it->print == print) {
+                    entries_.splice(entries_.begin(), entries_, it);
+                    return entries_.front().ctx;
+                }
+                tfhe_amd_ctx_destroy(it->ctx);  // same address, different contents
+                entries_.erase(it);
+                break;
+            }
+        const std::vector<uint32_t> bk = make_bk(), ks = make_ks();
+        tfhe_amd_ctx* ctx = nullptr;
+        check(tfhe_amd_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(),
+                                  device(), TFHE_AMD_CTX_DEFAULT, &ctx),
+              "tfhe_amd_ctx_create");
+        entries_.push_front(Entry{bk_id, ks_id, print, params, ctx});
+        if (entries_.size() > kMaxEntries) {
+            tfhe_amd_ctx_destroy(entries_.back().ctx);
+            entries_.pop_back();
+        }
+        return ctx;
+    }
+};
+
+inline ContextCache& cache() {
+    static ContextCache c;
+    return c;
+}
+
+// fingerprint helpers: a few words sampled across the key
+inline uint64_t mix(uint64_t h, uint32_t v) { return (h ^ v) * 0x100000001B3ULL; }
+template <int N, int R, int K1, int TLWE_N>
+uint64_t fingerprint(const Vector<Matrix<Polynomial<TorusValue, N>, R, K1>, TLWE_N>& bk) {
+    uint64_t h = 0xCBF29CE484222325ULL;
+    for (int i = 0; i < TLWE_N; i += (TLWE_N > 16 ? TLWE_N / 16 : 1))
+        for (int r = 0; r < R; r++) h = mix(h, bk[i][r][K1 - 1][(i * 7 + r) % N].get_raw_value());
+    return h;
+}
+template <int W, int B, int T, int N_LV1>
+uint64_t fingerprint(const Vector<Vector<Vector<Vector<TorusValue, W>, B>, T>, N_LV1>& ks) {
+    uint64_t h = 0x84222325CBF29CE4ULL;
+    for (int i = 0; i < N_LV1; i += (N_LV1 > 16 ? N_LV1 / 16 : 1))
+        for (int m = 0; m < T; m++) h = mix(h, ks[i][m][B - 1][(i + m) % W].get_raw_value());
+    return h;
+}
+
+}  // namespace gpu
+}  // namespace TFHE

@@ -1,0 +1,112 @@
+// Drop-in for KowerKoint/TFHE's src/hom_nand.hpp: the gate API.  Key generation, encryption and
+// decryption run on the host; nand() is evaluated on the GPU through libtfhe_amd, and
+// nand_batch() (not in the reference) evaluates many independent gates in one call.
+//
+// Unlike the reference (src/hom_nand.hpp:26,49) the TRGSW member honours TRLWEParameter, so the
+// class can be instantiated with a non-default ring.
+#pragma once
+
+#include <vector>
+
+#include "gpu_dispatch.hpp"
+#include "tlwe_key_switching.hpp"
+#include "trgsw.hpp"
+
+namespace TFHE {
+template <typename TLWELv0Parameter = TLWEParameter128BitSecurity, typename TLWELv1Parameter = TLWELv1ParameterDefault,
+          typename TRLWEParameter = TRLWEParameterDefault, typename TRGSWParameter = TRGSWParameterDefault,
+          typename TLWEKeySwitchingParameter = TLWEKeySwitchingParameterDefault>
+class HomNAND {
+    constexpr static int N_LV0 = TLWELv0Parameter::N;
+    constexpr static int N_LV1 = TLWELv1Parameter::N;
+    constexpr static int N = TRLWEParameter::N;
+    constexpr static int K = TRGSWParameter::K;
+    constexpr static int BG_BIT = TRGSWParameter::BG_BIT;
+    constexpr static int L = TRGSWParameter::L;
+    constexpr static int BASE_BIT = TLWEKeySwitchingParameter::BASE_BIT;
+    constexpr static int T = TLWEKeySwitchingParameter::T;
+    static_assert(N_LV1 == N * K, "the lv1 dimension is the flattened ring key");
+
+private:
+    TLWE<TLWELv0Parameter> tlwe_lv0;
+    TLWE<TLWELv1Parameter> tlwe_lv1;
+    TRLWE<TRLWEParameter> trlwe;
+    TRGSW<TRGSWParameter, TRLWEParameter> trgsw;
+    TLWEKeySwitching<decltype(tlwe_lv0), decltype(tlwe_lv1), TLWEKeySwitchingParameter> key_switching;
+
+public:
+    struct SecretKey {
+        Vector<bool, N_LV0> tlwe_lv0_s;
+        Vector<Polynomial<bool, N>, K> trlwe_s;
+    };
+    struct EvaluateKey {
+        Vector<Matrix<Polynomial<TorusValue, N>, (K + 1) * L, K + 1>, N_LV0> bk;
+        Vector<Vector<Vector<Vector<TorusValue, N_LV0 + 1>, (1 << BASE_BIT)>, T>, N_LV1> ks;
+    };
+    using Cipher = Vector<TorusValue, N_LV0 + 1>;
+
+    HomNAND() : tlwe_lv0{}, tlwe_lv1{}, trlwe{}, trgsw{trlwe}, key_switching{tlwe_lv0} {}
+    // reproducible key material and encryption noise
+    explicit HomNAND(uint64_t seed)
+        : tlwe_lv0{seed}, tlwe_lv1{seed + 1}, trlwe{seed + 2}, trgsw{trlwe}, key_switching{tlwe_lv0} {}
+
+    SecretKey generate_secret_key() { return {tlwe_lv0.generate_s(), trlwe.generate_s()}; }
+
+    EvaluateKey make_evaluate_key(const SecretKey& secret_key) {
+        EvaluateKey evaluate_key;
+        evaluate_key.bk = trgsw.make_bk(secret_key.tlwe_lv0_s, secret_key.trlwe_s);
+        evaluate_key.ks =
+            key_switching.make_ks(secret_key.tlwe_lv0_s, trlwe.extract_tlwe_lv0_key(secret_key.trlwe_s));
+        return evaluate_key;
+    }
+
+    Cipher encrypt(bool m, const SecretKey& secret_key) {
+        return tlwe_lv0.encrypt_single_binary(m, secret_key.tlwe_lv0_s);
+    }
+    bool decrypt(const Cipher& c, const SecretKey& secret_key) {
+        return tlwe_lv0.decrypt_single_binary(c, secret_key.tlwe_lv0_s);
+    }
+
+    static tfhe_amd_params params() {
+        tfhe_amd_params p;
+        p.n = N_LV0; p.N = N; p.K = K; p.bg_bit = BG_BIT; p.L = L; p.T = T; p.base_bit = BASE_BIT;
+        return p;
+    }
+
+    // The device copy of an evaluation key; built on first use and cached on the key's identity.
+    tfhe_amd_ctx* context(const EvaluateKey& evaluate_key) {
+        return gpu::cache().get(
+            params(), &evaluate_key.bk, &evaluate_key.ks,
+            gpu::fingerprint(evaluate_key.bk) ^ gpu::fingerprint(evaluate_key.ks),
+            [&] { return gpu::flatten_bk(evaluate_key.bk); }, [&] { return gpu::flatten_ks(evaluate_key.ks); });
+    }
+
+    // (1/8, 0..0) - a - b, bootstrapped to lv1 and key-switched back (reference src/hom_nand.hpp:74-81)
+    Cipher nand(const Cipher& a, const Cipher& b, const EvaluateKey& evaluate_key) {
+        std::vector<uint32_t> fa, fb, out((size_t)N_LV0 + 1);
+        gpu::put(fa, a);
+        gpu::put(fb, b);
+        gpu::check(tfhe_amd_nand_batch(context(evaluate_key), fa.data(), fb.data(), out.data(), 1), "nand");
+        return gpu::take_vector<N_LV0 + 1>(out.data());
+    }
+
+    // out[g] = nand(a[g], b[g]) for independent gates, one GPU call
+    std::vector<Cipher> nand_batch(const std::vector<Cipher>& a, const std::vector<Cipher>& b,
+                                   const EvaluateKey& evaluate_key) {
+        if (a.size() != b.size()) throw std::invalid_argument("nand_batch: a and b differ in length");
+        const size_t G = a.size(), W = (size_t)N_LV0 + 1;
+        std::vector<uint32_t> fa, fb, out(G * W);
+        fa.reserve(G * W);
+        fb.reserve(G * W);
+        for (size_t g = 0; g < G; g++) {
+            gpu::put(fa, a[g]);
+            gpu::put(fb, b[g]);
+        }
+        gpu::check(tfhe_amd_nand_batch(context(evaluate_key), fa.data(), fb.data(), out.data(), G), "nand_batch");
+        std::vector<Cipher> res;
+        res.reserve(G);
+        for (size_t g = 0; g < G; g++) res.push_back(gpu::take_vector<N_LV0 + 1>(out.data() + g * W));
+        return res;
+    }
+};
+}  // namespace TFHE

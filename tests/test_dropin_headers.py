@@ -1,0 +1,38 @@
+"""The drop-in C++ headers (src/*.hpp): behavioural tests in tests/cpp/test_dropin.cpp, and the
+reference's OWN test driver compiled unmodified against these headers (oracle/_ref/ref_tests_dropin,
+built only in the development container; skipped where the binary is absent)."""
+import pathlib
+import subprocess
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+DROPIN = ROOT / "tests" / "cpp" / "dropin_test"
+REF_DRIVER = ROOT / "oracle" / "_ref" / "ref_tests_dropin"
+
+
+def _run(cmd, timeout):
+    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_dropin_host_group():
+    assert DROPIN.exists(), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    assert "host group ok" in _run([DROPIN, "host"], 300)
+
+
+@pytest.mark.gpu
+def test_dropin_gpu_group():
+    # CMUX, bootstrapping, key switching, 50 chained NANDs + nand_batch, HomNAND on another ring
+    assert "gpu group ok" in _run([DROPIN, "gpu"], 600)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["PolynomialXExp", "TLWE", "TRLWE", "CMUX", "KeySwitching", "HomNAND"])
+def test_reference_driver_on_dropin_headers(name):
+    """reference test/main.cpp:13-224, unmodified, against src/*.hpp + libtfhe_amd.
+    test_PolynomialXExp FAILS on the reference itself (its FFT product is not exact) and passes here."""
+    if not REF_DRIVER.exists():
+        pytest.skip("oracle/_ref/ref_tests_dropin not built (needs /root/reference at build time)")
+    assert f"test_{name} passed" in _run([REF_DRIVER, name], 900)
