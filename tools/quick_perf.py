@@ -30,3 +30,13 @@ for G in [int(x) for x in sys.argv[1:]] or [256, 1024, 2048, 4096, 8192]:
     dt = (time.time() - t0) / reps
     br, ksm, n = ctx.timing()
     print(f"G={G:6d}  {dt*1e3:9.2f} ms/batch  {G/dt:10.0f} gates/s   BR {br/n:9.2f} ms  KS {ksm/n:8.2f} ms", flush=True)
+
+# host-pointer entry point (PCIe inclusive)
+G = 8192
+a = rs.randint(0, 2**32, size=(G, p.n1), dtype=np.uint64).astype(np.uint32)
+b = rs.randint(0, 2**32, size=(G, p.n1), dtype=np.uint64).astype(np.uint32)
+ctx.nand(a[:64], b[:64])
+t0 = time.time()
+ctx.nand(a, b)
+dt = time.time() - t0
+print(f"host-pointer nand, G={G}: {dt*1e3:.2f} ms  {G/dt:.0f} gates/s (PCIe inclusive, pageable host memory)", flush=True)
