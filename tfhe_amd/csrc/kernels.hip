@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) bk_transform_512_kernel(const NttUniform 
     double x[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = (double)(int32_t)src[64 * k + lane];
-    ntt512_forward<false>(x, u, s_tw, s_tr[wave], lane);
+    ntt512_forward<false, true>(x, u, s_tw, s_tr[wave], lane);
     d2* dst = bk_ntt + (size_t)poly * (kN / 2);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
@@ -109,16 +109,31 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
     }
     wave_lds_fence();
 
-    // offset = rounding half-unit below the last level + 2^(BG-1) at every level's position
-    uint32_t offset = 1u << (32 - L * BG - 1);
+    // offset = rounding half-unit below the last level + 2^(BG-1) at every level's position;
+    // flip = the top bit of every level's field: digit_l = signed field l of ((a + offset) ^ flip)
+    uint32_t offset = 1u << (32 - L * BG - 1), flip = 0u;
 #pragma unroll
-    for (int l = 0; l < L; l++) offset += 1u << (32 - BG * (l + 1) + BG - 1);
+    for (int l = 0; l < L; l++) {
+        offset += 1u << (32 - BG * (l + 1) + BG - 1);
+        flip |= 1u << (32 - BG * (l + 1) + BG - 1);
+    }
 
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
         if ((i & 63) == 0) cvals = (i + lane < n) ? cg[1 + i + lane] : 0u;
         const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cvals, i & 63);
         const int abar = (int)((ci + (1u << 21)) >> 22);  // round(a_i * 2N), in [0, 2N]
+
+        // acc * X^abar at position j = 64k + lane: coefficient (j - abar) mod 2N of the
+        // antiperiodic extension, i.e. +-acc[(j - abar) mod N]
+        int src[8];
+        uint32_t neg[8];  // all ones where the source coefficient enters negated
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int sidx = (64 * k + lane - abar) & (2 * kN - 1);
+            src[k] = sidx & (kN - 1);
+            neg[k] = 0u - (uint32_t)((sidx >> 9) & 1);
+        }
 
         double out[K1][8];
 #pragma unroll
@@ -128,32 +143,49 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
 
         const d2* bk_row = bk_ntt + (size_t)i * (R * K1 * (kN / 2));
 #pragma unroll 1
-        for (int r = 0; r < R; r++) {
-            const int q = r / L, level = r % L;
-            const int shift = 32 - BG * (level + 1);
-            double x[8];
+        for (int q = 0; q < K1; q++) {
+            // t = (acc_q * X^abar - acc_q + offset) ^ flip, all levels' digits at once
+            uint32_t t[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int j = 64 * k + lane;
-                const int s = (j - abar) & (2 * kN - 1);
-                uint32_t v = acc[q][s & (kN - 1)];
-                v = (s & kN) ? 0u - v : v;
-                const uint32_t t = v - acc[q][j] + offset;
-                x[k] = (double)((int)((t >> shift) & ((1u << BG) - 1)) - (1 << (BG - 1)));
+                const uint32_t v = acc[q][src[k]];
+                t[k] = ((((v ^ neg[k]) - neg[k]) - acc[q][64 * k + lane]) + offset) ^ flip;
             }
-            ntt512_forward<true>(x, u, s_tw, tr, lane);
-            const d2* bk_poly = bk_row + (size_t)r * K1 * (kN / 2);
 #pragma unroll
-            for (int col = 0; col < K1; col++) {
+            for (int level = 0; level < L; level++) {
+                double x[8];
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const d2 y = bk_poly[col * (kN / 2) + kk * 64 + lane];
-                    out[col][2 * kk] += mulmod_var(x[2 * kk], y.x, p, pinv);
-                    out[col][2 * kk + 1] += mulmod_var(x[2 * kk + 1], y.y, p, pinv);
+                for (int k = 0; k < 8; k++)
+                    x[k] = (double)(((int32_t)(t[k] << (BG * level))) >> (32 - BG));  // signed field `level`
+                // the key row of this digit polynomial is requested before the transform and
+                // consumed after it, so the L2 / Infinity-Cache latency hides under the butterflies
+                const d2* bk_poly = bk_row + (size_t)(q * L + level) * K1 * (kN / 2);
+                d2 y[K1][4];
+#pragma unroll
+                for (int col = 0; col < K1; col++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) y[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+                // |x| <= 3.2 p: every product below is at most (0.5 + 1.5 * 3.2 / 5.26) p = 1.41 p
+                ntt512_forward<true, false>(x, u, s_tw, tr, lane);
+#pragma unroll
+                for (int col = 0; col < K1; col++) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        out[col][2 * kk] += mulmod_var(x[2 * kk], y[col][kk].x, p, pinv);
+                        out[col][2 * kk + 1] += mulmod_var(x[2 * kk + 1], y[col][kk].y, p, pinv);
+                    }
+                }
+                // three products sum to <= 4.24 p; reducing after every third keeps the running
+                // sum below 0.5 p + 4.24 p = 4.74 p < 2^53 = 5.26 p
+                if ((q * L + level) % 3 == 2 && q * L + level != R - 1) {
+#pragma unroll
+                    for (int col = 0; col < K1; col++)
+#pragma unroll
+                        for (int k = 0; k < 8; k++) out[col][k] = reduce(out[col][k], p, pinv);
                 }
             }
         }
-        // |out| <= R * 0.64 p <= 3.9 p for R = 6
+        // |out| <= 4.74 p
 #pragma unroll
         for (int col = 0; col < K1; col++) {
             ntt512_inverse(out[col], u, s_tw, tr, lane);

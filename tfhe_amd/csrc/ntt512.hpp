@@ -177,12 +177,12 @@ __device__ __forceinline__ void transpose_b_to_a(double (&x)[8], double* tr, int
 }
 
 // Forward transform.  In: layout A, |x| <= 2^31 (SMALL: |x| <= 2^7, 8-bit gadget digits).
-// Out: layout C (bit-reversed spectrum order), |x| <= p/2.
+// Out: layout C (bit-reversed spectrum order); |x| <= p/2 with FINAL_REDUCE, else |x| <= 3.2 p.
 //
 // Growth between reductions, in units of p (a CT butterfly maps bound B to
 // B + 0.5 + 0.75 B / 5.26): after the layout-A stages <= 1.72, after layout B <= 4.29,
 // the distance-4 stage reduces its additive inputs, after layout C <= 3.2 < 5.26.
-template <bool SMALL>
+template <bool SMALL, bool FINAL_REDUCE>
 __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform& u, const d2* s_tw,
                                                double* tr, int lane) {
     const double p = u.p, pinv = u.pinv;
@@ -223,8 +223,10 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform&
     transpose_b_to_c(x, tr, lane);
     load_tw7(t, s_tw + kTwFwdC + 7 * lane);
     ct8<true>(x, t, p, pinv);
+    if (FINAL_REDUCE) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+        for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+    }
 }
 
 // Inverse transform without the 1/N factor.  In: layout C, |x| < 2^53.  Out: layout A,
