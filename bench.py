@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--gates-per-gpu", type=int, default=8192,
                     help="batch per GPU per step (8192 = one GPU's shard of the 65,536-gate configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the 1,024-gate and single-gate timings (for clean rocprofv3 kernel averages)")
     ap.add_argument("--cpu-sample-gates", type=int, default=32)
     args = ap.parse_args()
 
@@ -175,8 +177,19 @@ def main():
                          "note": "peak = 39.3e12 FP64 lane-instructions/s / 7.69 FP64 instructions per modmul-equivalent"},
             "key_broadcast_s": t_bcast,
         }
+        # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE),
+        # which cannot run inside this process: the committed summary of the latest passes is quoted
+        pmc = sorted((ROOT / "profiles").glob("*_pmc_summary.json"))
+        if pmc:
+            k = json.loads(pmc[-1].read_text())["kernels"].get("blind_rotate_512_kernel", {})
+            if "hbm_bytes_per_launch" in k:
+                line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = (f"profiles/{pmc[-1].name}: (2 x FETCH_SIZE + WRITE_SIZE) per launch of "
+                                                      "8192 gates; the NTT-domain key (46.9 MB) is re-streamed from the "
+                                                      "Infinity Cache once per XCD and wave generation, L2 hit rate 99 %")
+                line["roofline"]["valu_pipe_busy"] = 2 * k.get("valu_active_share_of_wave_cycles", 0.0)
         # the 1,024-gate single-GPU configuration and single-gate latency, measured beside it
-        if world == 1:
+        if world == 1 and not args.no_extras:
             extra = {}
             for g_small in (1024, 1):
                 ctx.nand_device(a[:g_small], b[:g_small], out[:g_small]); ctx.synchronize()
@@ -189,6 +202,7 @@ def main():
                 extra[f"batch_{g_small}"] = {"ms": dt * 1e3, "gates_per_s": g_small / dt}
             line["other_batches"] = extra
             line["single_gate_latency_ms"] = extra["batch_1"]["ms"]
+        if world == 1:
             if not args.no_cpu_baseline:
                 threads = min(16, os.cpu_count() or 1)
                 line["cpu_baseline"] = cpu_baseline(p, args.cpu_sample_gates, threads)
