@@ -49,6 +49,11 @@ enum {
 
 typedef struct tfhe_amd_ctx tfhe_amd_ctx;
 
+/* `stream` arguments of the _device entry points: NULL = the context's own (non-blocking)
+ * stream; TFHE_AMD_DEFAULT_STREAM = the device's default (null) stream, whose handle is itself
+ * NULL and therefore needs a name of its own; anything else = a hipStream_t. */
+#define TFHE_AMD_DEFAULT_STREAM ((void*)(intptr_t)-1)
+
 /* Fills *p with the reference's default parameter set. */
 void tfhe_amd_params_default(tfhe_amd_params* p);
 /* 0 if kernels exist for *p, else TFHE_AMD_ERR_UNSUPPORTED / TFHE_AMD_ERR_ARGUMENT. */
@@ -59,8 +64,13 @@ size_t tfhe_amd_ks_words(const tfhe_amd_params* p);
 enum {
     TFHE_AMD_CTX_DEFAULT = 0,
     TFHE_AMD_CTX_KEYS_ON_DEVICE = 1,  /* bk / ks point to memory of GPU `device` (e.g. after a broadcast) */
-    TFHE_AMD_CTX_GENERIC_KERNELS = 2  /* use the parameter-generic exact O(N^2) kernels even where a
+    TFHE_AMD_CTX_GENERIC_KERNELS = 2, /* use the parameter-generic exact O(N^2) kernels even where a
                                          specialised NTT kernel exists (cross-checking) */
+    /* The specialised blind rotation has two forms with identical results: one gate per wave
+     * (throughput) and one gate per workgroup (latency).  By default batches of at most 512 gates
+     * take the latency form; these flags pin one form. */
+    TFHE_AMD_CTX_LATENCY_FORM = 4,
+    TFHE_AMD_CTX_THROUGHPUT_FORM = 8
 };
 
 /* Replaces holding an EvaluateKey (reference src/hom_nand.hpp:36-42): uploads the keys to GPU

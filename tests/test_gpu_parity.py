@@ -113,3 +113,55 @@ def test_empty_batch(ctx, keys):
     p = keys[0]
     out = ctx.nand(np.zeros((0, p.n + 1), np.uint32), np.zeros((0, p.n + 1), np.uint32))
     assert out.shape == (0, p.n + 1)
+
+
+def test_latency_and_throughput_forms_agree(keys, octx):
+    """One gate per workgroup (latency form) and one gate per wave (throughput form) are the
+    same arithmetic: identical ciphertexts, both equal to the oracle."""
+    import tfhe_amd
+
+    p, s0, _, bk, ks = keys
+    _, _, a, b = _inputs(p, s0, 7, seed=23)
+    want = octx.nand_batch(a, b)
+    for form in ("latency", "throughput"):
+        with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks, form=form) as ctx:
+            assert np.array_equal(ctx.nand(a, b), want), form
+            c = np.stack([O.nand_combine(x, y, p) for x, y in zip(a, b)])
+            assert np.array_equal(ctx.blind_rotate(c[:2])[0], octx.blind_rotate(c[0])), form
+
+
+def test_config4_ripple_carry_adder(keys, ctx, octx):
+    """32-bit ripple-carry adder from NAND only, gates batched per dependency level, wires
+    resident on the GPU.  Decrypted sum = a + b; on an 8-bit instance every wire equals the
+    oracle evaluated in the same level order."""
+    import torch
+
+    from tfhe_amd import circuit as C
+
+    p, s0, _, _, _ = keys
+    rs = np.random.RandomState(3)
+    for bits, check_wires in ((8, True), (32, False)):
+        gates, n_wires, a, b, zero, sums, cout = C.ripple_carry_adder(bits)
+        x, y = int(rs.randint(0, 2**bits, dtype=np.uint64)), int(rs.randint(0, 2**bits, dtype=np.uint64))
+        r = O.rng(100 + bits)
+        w = np.zeros((n_wires, p.n + 1), dtype=np.uint32)
+        w[a] = O.encrypt_bits([(x >> i) & 1 for i in range(bits)], s0, p, r)
+        w[b] = O.encrypt_bits([(y >> i) & 1 for i in range(bits)], s0, p, r)
+        w[zero] = C.trivial_bit(0, p.n + 1)
+        dw = torch.from_numpy(w.view(np.int32).copy()).cuda()
+
+        def gpu_nand(u, v):
+            # on torch's current stream, so the gathers before and the scatter after are ordered
+            out = torch.empty_like(u)
+            ctx.nand_device(u, v, out, stream=torch.cuda.current_stream())
+            return out
+
+        levels = C.levelize(gates, n_wires)
+        assert C.evaluate(gates, dw, gpu_nand, levels) == 3 + 2 * bits + 1
+        torch.cuda.synchronize()
+        got = dw.cpu().numpy().view(np.uint32)
+        out_bits = O.decrypt_bits(got[sums + [cout]], s0, p)
+        assert sum(int(v) << i for i, v in enumerate(out_bits)) == x + y
+        if check_wires:
+            C.evaluate(gates, w, lambda u, v: octx.nand_batch(u, v), levels)
+            assert np.array_equal(got, w)

@@ -138,17 +138,19 @@ class Context:
     """Device-resident evaluation key: what holding a HomNAND::EvaluateKey
     (reference src/hom_nand.hpp:36-42) becomes on the GPU."""
 
-    KEYS_ON_DEVICE, GENERIC_KERNELS = 1, 2
+    KEYS_ON_DEVICE, GENERIC_KERNELS, LATENCY_FORM, THROUGHPUT_FORM = 1, 2, 4, 8
 
-    def __init__(self, params, bk, ks, device=0, keys_on_device=False, generic_kernels=False):
+    def __init__(self, params, bk, ks, device=0, keys_on_device=False, generic_kernels=False, form=None):
         """bk / ks: numpy uint32 arrays (host) or 32-bit torch GPU tensors (keys_on_device);
         either may be None.  generic_kernels: use the parameter-generic exact O(N^2) kernels
-        even where a specialised NTT kernel exists."""
+        even where a specialised NTT kernel exists.  form: None (by batch size), 'latency' or
+        'throughput' for the specialised blind rotation."""
         lib = library()
         self.params = params
         self.device = int(device)
         self._h = C.c_void_p()
         flags = (self.KEYS_ON_DEVICE if keys_on_device else 0) | (self.GENERIC_KERNELS if generic_kernels else 0)
+        flags |= {None: 0, 'latency': self.LATENCY_FORM, 'throughput': self.THROUGHPUT_FORM}[form]
         bk_words, ks_words = lib.tfhe_amd_bk_words(C.byref(params)), lib.tfhe_amd_ks_words(C.byref(params))
         if keys_on_device:
             bk_p = _dev_ptr(bk, bk_words) if bk is not None else None
@@ -234,7 +236,12 @@ class Context:
     # ---- GPU tensors (torch), asynchronous on `stream` (a torch stream or None) -------------
     @staticmethod
     def _stream_ptr(stream):
-        return C.c_void_p(stream.cuda_stream) if stream is not None else None
+        """None -> the context's own stream; a torch stream -> that stream (the default stream's
+        handle is 0, which the C ABI spells TFHE_AMD_DEFAULT_STREAM = (void*)-1)."""
+        if stream is None:
+            return None
+        handle = stream.cuda_stream
+        return C.c_void_p(handle if handle else C.c_void_p(-1).value)
 
     def nand_device(self, a, b, out, stream=None):
         g = a.shape[0]

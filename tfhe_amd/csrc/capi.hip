@@ -67,6 +67,7 @@ struct tfhe_amd_ctx {
     uint32_t* d_bk_raw = nullptr;  // generic path
     uint32_t* d_ks = nullptr;      // packed
     bool has_bk = false, has_ks = false;
+    int form = 0;                  // blind-rotation kernel form: 0 auto, 1 latency, 2 throughput
     hipStream_t stream = nullptr;
     // workspace, grown on demand
     uint32_t* d_c = nullptr;
@@ -177,6 +178,12 @@ int drain_timing(tfhe_amd_ctx* ctx, int keep) {
     return TFHE_AMD_OK;
 }
 
+hipStream_t pick_stream(const tfhe_amd_ctx* ctx, void* stream) {
+    if (!stream) return ctx->stream;
+    if (stream == TFHE_AMD_DEFAULT_STREAM) return nullptr;
+    return (hipStream_t)stream;
+}
+
 int need_bk(const tfhe_amd_ctx* ctx) {
     return ctx->has_bk ? TFHE_AMD_OK : fail(TFHE_AMD_ERR_ARGUMENT, "context holds no bootstrapping key");
 }
@@ -197,7 +204,7 @@ int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, u
     const tfhe_amd_params& p = ctx->p;
     if (ctx->fast)
         HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)n_gates, p.n, p.K, p.L,
-                                        extract, s));
+                                        extract, ctx->form, s));
     else
         HIP_TRY(launch_blind_rotate_generic(ctx->d_bk_raw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit, extract,
                                             s));
@@ -330,6 +337,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     ctx->p = *p;
     ctx->device = device;
     ctx->fast = fast_supported(p) && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
+    ctx->form = (flags & TFHE_AMD_CTX_LATENCY_FORM) ? 1 : (flags & TFHE_AMD_CTX_THROUGHPUT_FORM) ? 2 : 0;
     auto bail = [&](hipError_t e, const char* what) {
         tfhe_amd_ctx_destroy(ctx);
         return fail(hip_code(e), std::string(what) + ": " + hipGetErrorString(e));
@@ -403,7 +411,7 @@ int tfhe_amd_bootstrap_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
     if ((rc = ensure_workspace(ctx, n_gates))) return rc;
-    return run_bootstrap(ctx, c, out, n_gates, stream ? (hipStream_t)stream : ctx->stream);
+    return run_bootstrap(ctx, c, out, n_gates, pick_stream(ctx, stream));
 }
 
 int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
@@ -413,7 +421,7 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
     if ((rc = ensure_workspace(ctx, n_gates))) return rc;
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = pick_stream(ctx, stream);
     HIP_TRY(launch_nand_combine(ctx->d_c, a, b, n_gates, ctx->p.n + 1, s));
     return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
 }
@@ -424,7 +432,7 @@ int tfhe_amd_gate_bootstrapping_batch_device(tfhe_amd_ctx* ctx, const uint32_t* 
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    return run_blind_rotate(ctx, c, nullptr, lv1, n_gates, 1, stream ? (hipStream_t)stream : ctx->stream);
+    return run_blind_rotate(ctx, c, nullptr, lv1, n_gates, 1, pick_stream(ctx, stream));
 }
 
 int tfhe_amd_blind_rotate_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* test_vector,
@@ -433,7 +441,7 @@ int tfhe_amd_blind_rotate_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, con
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    return run_blind_rotate(ctx, c, test_vector, acc, n_gates, 0, stream ? (hipStream_t)stream : ctx->stream);
+    return run_blind_rotate(ctx, c, test_vector, acc, n_gates, 0, pick_stream(ctx, stream));
 }
 
 int tfhe_amd_identity_key_switch_batch_device(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out,
@@ -442,7 +450,7 @@ int tfhe_amd_identity_key_switch_batch_device(tfhe_amd_ctx* ctx, const uint32_t*
     if (rc || n_gates == 0) return rc;
     if ((rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    return run_key_switch(ctx, lv1, out, n_gates, stream ? (hipStream_t)stream : ctx->stream);
+    return run_key_switch(ctx, lv1, out, n_gates, pick_stream(ctx, stream));
 }
 
 // ---- host-pointer entry points --------------------------------------------------------------

@@ -219,6 +219,121 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
 }
 
 // ------------------------------------------------------------------------------------------
+// Blind rotation for small batches (latency form).  One WORKGROUP owns one gate and its
+// (K+1)*L waves split each step: wave r decomposes, transforms and multiplies digit polynomial
+// r (phase 1, partial products to LDS); after a barrier waves 0..K sum the partial products of
+// their column, inverse-transform and update the accumulator (phase 2).  The dependent chain per
+// step is one forward transform, one multiply, one inverse transform instead of six, eighteen
+// and three.  Same arithmetic, same results as blind_rotate_512_kernel.
+// ------------------------------------------------------------------------------------------
+template <int K, int L>
+__global__ void __launch_bounds__(64 * (K + 1) * L, 1)
+blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw, const d2* __restrict__ bk_ntt,
+                                const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv,
+                                uint32_t* __restrict__ out, int n_gates, int n, int extract) {
+    constexpr int K1 = K + 1, R = K1 * L, BG = 8, THREADS = 64 * R;
+    __shared__ d2 s_tw[kTwPairs];
+    __shared__ double s_tr[R][kTrPad];
+    __shared__ uint32_t s_acc[K1][kN];
+    __shared__ double s_part[R][K1][kN];  // [digit polynomial][column][register k * 64 + lane]
+
+    for (int i = threadIdx.x; i < kTwPairs; i += THREADS) s_tw[i] = tw[i];
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int gate = blockIdx.x;
+    const uint32_t* cg = c + (size_t)gate * (n + 1);
+    const double p = u.p, pinv = u.pinv;
+    double* tr = s_tr[r];
+
+    {
+        const int bbar = (int)(cg[0] >> 22);
+        for (int e = threadIdx.x; e < K1 * kN; e += THREADS) {
+            const int q = e / kN, j = e - q * kN;
+            const int s = (j + bbar) & (2 * kN - 1);
+            const uint32_t v = tv ? tv[q * kN + (s & (kN - 1))] : (q == 0 ? (1u << 29) : 0u);
+            s_acc[q][j] = (s & kN) ? 0u - v : v;
+        }
+    }
+    __syncthreads();
+
+    uint32_t offset = 1u << (32 - L * BG - 1), flip = 0u;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        offset += 1u << (32 - BG * (l + 1) + BG - 1);
+        flip |= 1u << (32 - BG * (l + 1) + BG - 1);
+    }
+    const int q = r / L, level = r % L;
+
+    uint32_t cvals = 0;
+    for (int i = 0; i < n; i++) {
+        if ((i & 63) == 0) cvals = (i + lane < n) ? cg[1 + i + lane] : 0u;
+        const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cvals, i & 63);
+        const int abar = (int)((ci + (1u << 21)) >> 22);
+
+        // ---- phase 1: digit polynomial r -> NTT -> products with key row r ----
+        const d2* bk_poly = bk_ntt + ((size_t)i * R + r) * K1 * (kN / 2);
+        d2 y[K1][4];
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) y[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = 64 * k + lane;
+            const int sidx = (j - abar) & (2 * kN - 1);
+            const uint32_t neg = 0u - (uint32_t)((sidx >> 9) & 1);
+            const uint32_t v = s_acc[q][sidx & (kN - 1)];
+            const uint32_t t = ((((v ^ neg) - neg) - s_acc[q][j]) + offset) ^ flip;
+            x[k] = (double)(((int32_t)(t << (BG * level))) >> (32 - BG));
+        }
+        ntt512_forward<true, false>(x, u, s_tw, tr, lane);
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                s_part[r][col][(2 * kk) * 64 + lane] = mulmod_var(x[2 * kk], y[col][kk].x, p, pinv);
+                s_part[r][col][(2 * kk + 1) * 64 + lane] = mulmod_var(x[2 * kk + 1], y[col][kk].y, p, pinv);
+            }
+        __syncthreads();
+
+        // ---- phase 2: column r of the result (waves 0..K) ----
+        if (r < K1) {
+            double sum[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum[k] = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) sum[k] += s_part[rr][r][k * 64 + lane];
+                // each product is <= 1.41 p: reduce after every third so the sum stays < 4.74 p
+                if (rr % 3 == 2 && rr != R - 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) sum[k] = reduce(sum[k], p, pinv);
+                }
+            }
+            ntt512_inverse(sum, u, s_tw, tr, lane);
+#pragma unroll
+            for (int k = 0; k < 8; k++) s_acc[r][64 * k + lane] += to_torus(sum[k], p, pinv);
+        }
+        __syncthreads();
+    }
+
+    if (!extract) {
+        uint32_t* o = out + (size_t)gate * (K1 * kN);
+        for (int e = threadIdx.x; e < K1 * kN; e += THREADS) o[e] = s_acc[e / kN][e % kN];
+        return;
+    }
+    uint32_t* o = out + (size_t)gate * (K * kN + 1);
+    if (threadIdx.x == 0) o[0] = s_acc[0][0];
+    for (int e = threadIdx.x; e < K * kN; e += THREADS) {
+        const int qq = e / kN, j = e - qq * kN;
+        const uint32_t v = s_acc[1 + qq][j];
+        if (j == 0) o[1 + qq * kN] = v;
+        else        o[1 + qq * kN + (kN - j)] = 0u - v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Identity key switch.
 //
 // Table layout on the device ("packed"): [N*K][T][2^bb - 1][ROWP] words, the never-read digit-0
@@ -409,15 +524,22 @@ hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint
     return hipGetLastError();
 }
 
+// Batches up to this size run one gate per workgroup (latency form); larger ones one gate per wave.
+constexpr int kLatencyMaxGates = 512;
+
 hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
                                    const uint32_t* tv, uint32_t* out, int n_gates, int n, int K, int L, int extract,
-                                   hipStream_t stream) {
+                                   int form, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((n_gates + 3) / 4);
-    if (K == 2 && L == 2)
+    if (!(K == 2 && L == 2)) return hipErrorInvalidValue;
+    const bool latency = form == 1 || (form == 0 && n_gates <= kLatencyMaxGates);
+    if (latency) {
+        blind_rotate_512_latency_kernel<2, 2><<<(unsigned)n_gates, 64 * 6, 0, stream>>>(u, tw, bk_ntt, c, tv, out,
+                                                                                      n_gates, n, extract);
+    } else {
+        const unsigned blocks = (unsigned)((n_gates + 3) / 4);
         blind_rotate_512_kernel<2, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, tv, out, n_gates, n, extract);
-    else
-        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -14,10 +14,11 @@ hipError_t launch_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b
 hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint32_t* bk, d2* bk_ntt, int n_polys,
                                    hipStream_t stream);
 // tv: test vector [K+1][N] shared by all gates or nullptr (gate bootstrapping); extract != 0
-// writes sample_extract_index(acc, 0), else the accumulator
+// writes sample_extract_index(acc, 0), else the accumulator.  form: 0 = choose by batch size,
+// 1 = one gate per workgroup (latency), 2 = one gate per wave (throughput)
 hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
                                    const uint32_t* tv, uint32_t* out, int n_gates, int n, int K, int L, int extract,
-                                   hipStream_t stream);
+                                   int form, hipStream_t stream);
 // exact O(N^2) kernels for any parameter set (generic_kernels.hip)
 bool generic_has_kernel(int N, int K, int L);
 hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
