@@ -143,3 +143,46 @@ def test_extreme_operands_stay_exact():
                 a_fast, a_gen = fast.blind_rotate(c, tv), gen.blind_rotate(c, tv)
                 assert np.array_equal(a_fast, a_gen), name
                 assert np.array_equal(a_fast[0], O.blind_rotate(c[0], bk, op, O.SCHOOLBOOK, tv=tv)), name
+
+
+def test_n2048_ntt_path_vs_generic_and_oracle():
+    """The N = 2048 set (K = 1, L = 3): workgroup NTT kernels with the split key vs the O(N^2)
+    wrap-around kernels vs the oracle, including key words at the ends of the range (each key
+    half then sits at the end of its own range)."""
+    import tfhe_amd
+
+    n = 3
+    p = tfhe_amd.Params(n, 2048, 1, 8, 3, 8, 2)
+    op = O.params_from(n, 2048, 1, 8, 3, 8, 2)
+    rs = np.random.RandomState(31)
+    keys = [rs.randint(0, 2**32, size=p.bk_shape(), dtype=np.uint64).astype(np.uint32),
+            np.full(p.bk_shape(), 0x80000000, dtype=np.uint32),
+            np.full(p.bk_shape(), 0x7FFF8000, dtype=np.uint32)]
+    c = rs.randint(0, 2**32, size=(5, n + 1), dtype=np.uint64).astype(np.uint32)
+    c[0, 1:] = 0x00100000  # rotate by one position every step
+    tv = rs.randint(0, 2**32, size=(2, 2048), dtype=np.uint64).astype(np.uint32)
+    for bk in keys:
+        with tfhe_amd.Context(p, bk, None) as fast, tfhe_amd.Context(p, bk, None, generic_kernels=True) as gen:
+            for t in (None, tv):
+                got = fast.blind_rotate(c, t)
+                assert np.array_equal(got, gen.blind_rotate(c, t))
+                assert np.array_equal(got[0], O.blind_rotate(c[0], bk, op, O.NTT, tv=t))
+            assert np.array_equal(fast.gate_bootstrapping_tlwe_to_tlwe(c), gen.gate_bootstrapping_tlwe_to_tlwe(c))
+
+
+def test_config5_n2048_nand_vs_oracle():
+    """N = 2048 stress set end to end (n = 800, K = 1, L = 3, T = 8): NAND gates bit-exact vs the
+    oracle and decrypting correctly."""
+    import tfhe_amd
+
+    op = O.params_n2048()
+    s0, sr, bk, ks = O.keyset(op, seed=4)
+    p = tfhe_amd.Params(op.n, op.N, op.K, op.bg_bit, op.L, op.T, op.base_bit)
+    r = O.rng(1)
+    bits_a, bits_b = np.arange(12) % 2, (np.arange(12) // 2) % 2
+    a, b = O.encrypt_bits(bits_a, s0, op, r), O.encrypt_bits(bits_b, s0, op, r)
+    want = O.Context(op, bk, ks).nand_batch(a, b)
+    with tfhe_amd.Context(p, bk, ks) as ctx:
+        got = ctx.nand(a, b)
+    assert np.array_equal(got, want)
+    assert np.array_equal(O.decrypt_bits(got, s0, op), 1 - (bits_a & bits_b))

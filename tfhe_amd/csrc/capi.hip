@@ -12,6 +12,7 @@
 #include "../../include/tfhe_amd.h"
 #include "field.hpp"
 #include "kernels.hpp"
+#include "ntt_wg.hpp"
 
 using namespace tfhe_amd;
 
@@ -61,6 +62,8 @@ struct tfhe_amd_ctx {
     tfhe_amd_params p{};
     int device = 0;
     bool fast = false;             // specialised NTT kernels (N = 512, K = 2, L = 2, 8-bit gadget)
+    bool wg = false;               // workgroup-cooperative NTT kernels (N = 2048 set)
+    int parts = 1, shift = 0;      // key split of the wg path
     NttUniform u{};
     d2* d_tw = nullptr;
     d2* d_bk_ntt = nullptr;        // fast path
@@ -136,6 +139,33 @@ std::vector<double> build_tw_block_512(const TwiddleSet& t) {
     return blk;
 }
 
+// twiddle table of the workgroup NTT: forward rows of groups 1.., then inverse rows (ntt_wg.hpp)
+template <int LOGN>
+std::vector<double> build_tw_table_wg(const TwiddleSet& t) {
+    using W = WgNtt<LOGN>;
+    std::vector<double> blk((size_t)W::TABLE_PAIRS * 2, 0.0);
+    auto put = [&](int pair, uint64_t v) {
+        const TwPair tp = tw_pair(v);
+        blk[(size_t)pair * 2] = tp.w;
+        blk[(size_t)pair * 2 + 1] = tp.wp;
+    };
+    for (int dir = 0; dir < 2; dir++) {
+        const std::vector<uint64_t>& tab = dir ? t.inv : t.fwd;
+        for (int g = 1; g < W::GROUPS; g++) {
+            const int full = g < W::GROUPS - 1 || W::LAST == 3;
+            const int m = full ? 1 << (3 * g) : 1 << (LOGN - 3);
+            for (int U = 0; U < W::rows(g); U++) {
+                const int row = dir * W::TABLE_ROWS + W::row_offset(g) + U;
+                if (full || W::LAST == 3) put(7 * row, tab[m + U]);
+                if (full || W::LAST >= 2)
+                    for (int h = 0; h < 2; h++) put(7 * row + 1 + h, tab[2 * m + 2 * U + h]);
+                for (int h = 0; h < 4; h++) put(7 * row + 3 + h, tab[4 * m + 4 * U + h]);
+            }
+        }
+    }
+    return blk;
+}
+
 size_t n1_of(const tfhe_amd_ctx* c) { return (size_t)c->p.n + 1; }
 size_t lv1_of(const tfhe_amd_ctx* c) { return (size_t)c->p.N * c->p.K + 1; }
 size_t trlwe_of(const tfhe_amd_ctx* c) { return (size_t)(c->p.K + 1) * c->p.N; }
@@ -205,6 +235,9 @@ int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, u
     if (ctx->fast)
         HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)n_gates, p.n, p.K, p.L,
                                         extract, ctx->form, s));
+    else if (ctx->wg)
+        HIP_TRY(launch_blind_rotate_wg(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, n_gates, p.n, p.N, p.K, p.L,
+                                       ctx->parts, ctx->shift, extract, s));
     else
         HIP_TRY(launch_blind_rotate_generic(ctx->d_bk_raw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit, extract,
                                             s));
@@ -337,6 +370,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     ctx->p = *p;
     ctx->device = device;
     ctx->fast = fast_supported(p) && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
+    ctx->wg = !ctx->fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit) && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
     ctx->form = (flags & TFHE_AMD_CTX_LATENCY_FORM) ? 1 : (flags & TFHE_AMD_CTX_THROUGHPUT_FORM) ? 2 : 0;
     auto bail = [&](hipError_t e, const char* what) {
         tfhe_amd_ctx_destroy(ctx);
@@ -367,6 +401,21 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
                 src = up_bk.as<uint32_t>();
             }
             CTX_TRY(launch_bk_transform_512(ctx->u, ctx->d_tw, src, ctx->d_bk_ntt, (int)(bk_words / p->N), ctx->stream));
+        } else if (ctx->wg) {
+            const TwiddleSet tw = make_twiddles(p->N);
+            build_uniform(ctx->u, tw);
+            const std::vector<double> blk = build_tw_table_wg<11>(tw);
+            wg_split(p->N, p->K, p->L, p->bg_bit, &ctx->parts, &ctx->shift);
+            CTX_TRY(hipMalloc(&ctx->d_tw, blk.size() * sizeof(double)));
+            CTX_TRY(hipMemcpy(ctx->d_tw, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));
+            CTX_TRY(hipMalloc(&ctx->d_bk_ntt, bk_words * ctx->parts * sizeof(double)));
+            if (!on_device) {
+                CTX_TRY(up_bk.alloc(bk_words * sizeof(uint32_t)));
+                CTX_TRY(hipMemcpyAsync(up_bk.p, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                src = up_bk.as<uint32_t>();
+            }
+            CTX_TRY(launch_bk_transform_wg(ctx->u, ctx->d_tw, src, ctx->d_bk_ntt, bk_words / p->N, p->N, ctx->parts,
+                                           ctx->shift, ctx->stream));
         } else {
             CTX_TRY(hipMalloc(&ctx->d_bk_raw, bk_words * sizeof(uint32_t)));
             CTX_TRY(hipMemcpyAsync(ctx->d_bk_raw, bk, bk_words * sizeof(uint32_t),

@@ -1,0 +1,182 @@
+// Workgroup-cooperative exact negacyclic NTT of length N = 2^LOGN (N >= 1024) over the same
+// prime field and with the same FP64 modular arithmetic as ntt512.hpp.  N/8 threads transform
+// one polynomial: 8 coefficients per thread, groups of up to three radix-2 stages in registers,
+// a transpose through LDS (one block barrier each, two alternating buffers) between groups.
+//
+// Stage s (distance N / 2^(s+1)) pairs positions that differ in bit beta = LOGN-1-s.  Group g
+// covers stages 3g .. 3g+2; its register layout keeps bits b+2..b of the position in the
+// register index k, with b = LOGN - 3(g+1), and spreads the other bits over the threads:
+//     position(t, k) = ((t >> b) << (b + 3)) | (k << b) | (t & (2^b - 1)).
+// When LOGN is not a multiple of 3 the last group uses b = 0 and applies only the remaining
+// one or two stages.  Twiddles: group 0 is thread-uniform (kernel argument); the other groups
+// read 7 (w, RN(w/p)) pairs per thread from a table row U = t >> b:
+//     [0] = tw[m + U], [1 + h] = tw[2m + 2U + h], [3 + h] = tw[4m + 4U + h],  m = 2^(3g)
+// (for the partial last group m = 2^(LOGN-3) and the unused leading entries are ignored).
+#pragma once
+
+#include "ntt512.hpp"
+
+namespace tfhe_amd {
+
+template <int LOGN>
+struct WgNtt {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int T = N / 8;                  // threads per polynomial
+    static constexpr int GROUPS = (LOGN + 2) / 3;
+    static constexpr int LAST = LOGN - 3 * (GROUPS - 1);  // stages in the last group: 1, 2 or 3
+    static constexpr int PAD = N + N / 8;            // transpose buffer, one pad slot per 8 positions
+
+    __host__ __device__ static constexpr int base(int g) { return (g == GROUPS - 1) ? 0 : LOGN - 3 * (g + 1); }
+    __host__ __device__ static constexpr int stages(int g) { return (g == GROUPS - 1) ? LAST : 3; }
+    __host__ __device__ static constexpr int rows(int g) { return T >> base(g); }
+    // table row offset (in rows) of group g >= 1 inside one direction's table
+    __host__ __device__ static constexpr int row_offset(int g) {
+        int o = 0;
+        for (int i = 1; i < g; i++) o += rows(i);
+        return o;
+    }
+    static constexpr int TABLE_ROWS = row_offset(GROUPS);  // per direction
+    static constexpr int TABLE_PAIRS = 2 * TABLE_ROWS * 7;  // forward then inverse
+
+    __device__ static __forceinline__ int position(int g, int t, int k) {
+        const int b = base(g);
+        return ((t >> b) << (b + 3)) | (k << b) | (t & ((1 << b) - 1));
+    }
+
+    // registers in layout `from` -> registers in layout `to`
+    __device__ static __forceinline__ void transpose(double (&x)[8], double* buf, int from, int to, int t) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) buf[pad_pos(position(from, t, k))] = x[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = buf[pad_pos(position(to, t, k))];
+    }
+
+    template <int STAGES, bool REDUCE_A>
+    __device__ static __forceinline__ void ct_group(double (&x)[8], const Tw7& tw, double p, double pinv) {
+        if (STAGES >= 3) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (REDUCE_A) x[k] = reduce(x[k], p, pinv);
+                bf_ct(x[k], x[k + 4], tw.w[0], tw.wp[0], p);
+            }
+        }
+        if (STAGES >= 2) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    if (REDUCE_A && STAGES == 2) x[4 * h + k] = reduce(x[4 * h + k], p, pinv);
+                    bf_ct(x[4 * h + k], x[4 * h + k + 2], tw.w[1 + h], tw.wp[1 + h], p);
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (REDUCE_A && STAGES == 1) x[2 * g] = reduce(x[2 * g], p, pinv);
+            bf_ct(x[2 * g], x[2 * g + 1], tw.w[3 + g], tw.wp[3 + g], p);
+        }
+    }
+
+    template <int STAGES>
+    __device__ static __forceinline__ void gs_group(double (&x)[8], const Tw7& tw, double p) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], tw.w[3 + g], tw.wp[3 + g], p);
+        if (STAGES >= 2) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], tw.w[1 + h], tw.wp[1 + h], p);
+        }
+        if (STAGES >= 3) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], tw.w[0], tw.wp[0], p);
+        }
+    }
+
+    // Forward.  In: group-0 layout (position k*T + t), |x| <= 2^31 (SMALL: |x| <= 2^7).
+    // Out: last group's layout (position 8t + k, bit-reversed spectrum order), |x| <= 3.2 p.
+    // Additive inputs are reduced at the first stage of groups >= 2 (SMALL) or >= 1; the bound
+    // then stays below 4.2 p at every stage for LOGN <= 12.
+    // `parity` selects the transpose buffer and is advanced once per transpose.
+    template <bool SMALL>
+    __device__ static __forceinline__ void forward(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
+                                                   double* bufs, int& parity, int t) {
+        const double p = u.p, pinv = u.pinv;
+        if (SMALL) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double a = x[k], b = x[k + 4];
+                x[k] = __builtin_fma(b, u.zI, a);
+                x[k + 4] = __builtin_fma(-b, u.zI, a);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double a = x[k], b = x[k + 2];
+                x[k] = __builtin_fma(b, u.z, a);
+                x[k + 2] = __builtin_fma(-b, u.z, a);
+            }
+#pragma unroll
+            for (int k = 4; k < 6; k++) bf_ct(x[k], x[k + 2], u.fw[3], u.fwp[3], p);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) bf_ct(x[k], x[k + 4], u.fw[1], u.fwp[1], p);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) bf_ct(x[4 * h + k], x[4 * h + k + 2], u.fw[2 + h], u.fwp[2 + h], p);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) bf_ct(x[2 * g], x[2 * g + 1], u.fw[4 + g], u.fwp[4 + g], p);
+
+#pragma unroll
+        for (int g = 1; g < GROUPS; g++) {
+            // keeps the compiler from hoisting every group's twiddle loads (28 registers each) to
+            // the top of the transform
+            __builtin_amdgcn_sched_barrier(0);
+            Tw7 tw;
+            load_tw7(tw, table + 7 * (row_offset(g) + (t >> base(g))));
+            transpose(x, bufs + (parity & 1) * PAD, g - 1, g, t);
+            parity++;
+            constexpr bool kAlways = !SMALL;
+            if (g == GROUPS - 1) {
+                ct_group<LAST, true>(x, tw, p, pinv);
+            } else if (g >= 2 || kAlways) {
+                ct_group<3, true>(x, tw, p, pinv);
+            } else {
+                ct_group<3, false>(x, tw, p, pinv);
+            }
+        }
+    }
+
+    // Inverse without the 1/N factor.  In: last group's layout, |x| < 2^53.  Out: group-0 layout,
+    // |x| <= 4 p.  Every group starts from |x| <= p/2.
+    __device__ static __forceinline__ void inverse(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
+                                                   double* bufs, int& parity, int t) {
+        const double p = u.p, pinv = u.pinv;
+        const d2* inv_table = table + 7 * TABLE_ROWS;
+#pragma unroll
+        for (int g = GROUPS - 1; g >= 1; g--) {
+            __builtin_amdgcn_sched_barrier(0);
+            Tw7 tw;
+            load_tw7(tw, inv_table + 7 * (row_offset(g) + (t >> base(g))));
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+            if (g == GROUPS - 1) gs_group<LAST>(x, tw, p);
+            else                 gs_group<3>(x, tw, p);
+            transpose(x, bufs + (parity & 1) * PAD, g, g - 1, t);
+            parity++;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+#pragma unroll
+        for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], u.iw[4 + g], u.iwp[4 + g], p);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], u.iw[2 + h], u.iwp[2 + h], p);
+#pragma unroll
+        for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], u.iw[1], u.iwp[1], p);
+    }
+};
+
+}  // namespace tfhe_amd

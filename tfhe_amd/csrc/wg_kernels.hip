@@ -1,0 +1,235 @@
+// Blind rotation for ring degrees N >= 1024 (the N = 2048 stress set): one workgroup of N/8
+// threads owns one gate and transforms every polynomial cooperatively (ntt_wg.hpp).
+//
+// The field's prime (p/2 = 2^49.6) is smaller than the largest negacyclic accumulation of these
+// sets ((K+1) L N 2^7 2^31 = 2^51.6 for N = 2048, K = 1, L = 3), so the bootstrapping key is split
+// before it is transformed: bk = hi * 2^shift + lo with signed halves, each half is transformed
+// and accumulated separately (each sum is then below 2^36), and the two exact integer results
+// are recombined modulo 2^32 after the inverse transforms.  Same reference semantics as
+// kernels.hip (reference src/trgsw.hpp:131-182).
+#include "kernels.hpp"
+#include "ntt_wg.hpp"
+
+namespace tfhe_amd {
+
+// signed split v = hi * 2^shift + lo, lo in [-2^(shift-1), 2^(shift-1))
+__device__ __forceinline__ int32_t split_lo(int32_t v, int shift) { return (int32_t)((uint32_t)v << (32 - shift)) >> (32 - shift); }
+
+// One workgroup per (polynomial, part).  Stored value: NTT(part of centred bk) / N, centred, in
+// the order [pair kk in 0..3][thread t][2] of the transform's output layout (position 8t + k).
+template <int LOGN>
+__global__ void __launch_bounds__(WgNtt<LOGN>::T)
+bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const uint32_t* __restrict__ bk,
+                       d2* __restrict__ bk_ntt, int parts, int shift) {
+    using W = WgNtt<LOGN>;
+    __shared__ double s_tr[2 * W::PAD];
+    const int t = threadIdx.x;
+    const size_t poly = blockIdx.x / parts;
+    const int part = blockIdx.x % parts;
+    const uint32_t* src = bk + poly * W::N;
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int32_t v = (int32_t)src[k * W::T + t];
+        int32_t piece = v;
+        if (parts == 2) {
+            const int32_t lo = split_lo(v, shift);
+            piece = part == 0 ? lo : (int32_t)(((int64_t)v - lo) >> shift);
+        }
+        x[k] = (double)piece;
+    }
+    int parity = 0;
+    W::template forward<false>(x, u, table, s_tr, parity, t);
+    // transformed key: [.. r][col][part], i.e. raw polynomial index * parts + part = blockIdx.x
+    d2* dst = bk_ntt + ((size_t)blockIdx.x) * (W::N / 2);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        d2 v;
+        v.x = reduce(mulmod_tw(x[2 * kk], u.ninv, u.ninvp, u.p), u.p, u.pinv);
+        v.y = reduce(mulmod_tw(x[2 * kk + 1], u.ninv, u.ninvp, u.p), u.p, u.pinv);
+        dst[kk * W::T + t] = v;
+    }
+}
+
+// Transformed key layout: [n][R][K1][parts] polynomials (part innermost), each [4][T][2] doubles.
+template <int LOGN, int K, int L, int PARTS>
+__global__ void __launch_bounds__(WgNtt<LOGN>::T)
+blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d2* __restrict__ bk_ntt,
+                       const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv, uint32_t* __restrict__ out,
+                       int n, int shift, int extract) {
+    using W = WgNtt<LOGN>;
+    constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L, BG = 8;
+    __shared__ double s_tr[2 * W::PAD];
+    __shared__ uint32_t s_acc[K1][N];
+    const int t = threadIdx.x;
+    const size_t gate = blockIdx.x;
+    const uint32_t* cg = c + gate * (size_t)(n + 1);
+    const double p = u.p, pinv = u.pinv;
+    constexpr int SH = 32 - (LOGN + 1);
+
+    {
+        const int bbar = (int)(cg[0] >> SH);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = k * T + t;
+            const int s = (j + bbar) & (2 * N - 1);
+#pragma unroll
+            for (int q = 0; q < K1; q++) {
+                const uint32_t v = tv ? tv[q * N + (s & (N - 1))] : (q == 0 ? (1u << 29) : 0u);
+                s_acc[q][j] = (s & N) ? 0u - v : v;
+            }
+        }
+    }
+    __syncthreads();
+
+    uint32_t offset = 1u << (32 - L * BG - 1), flip = 0u;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        offset += 1u << (32 - BG * (l + 1) + BG - 1);
+        flip |= 1u << (32 - BG * (l + 1) + BG - 1);
+    }
+
+    int parity = 0;
+    for (int i = 0; i < n; i++) {
+        const int abar = (int)((cg[1 + i] + (1u << (SH - 1))) >> SH);
+        int src[8];
+        uint32_t neg[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int sidx = (k * T + t - abar) & (2 * N - 1);
+            src[k] = sidx & (N - 1);
+            neg[k] = 0u - (uint32_t)((sidx >> LOGN) & 1);
+        }
+
+        double acc_ntt[K1][PARTS][8];
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int part = 0; part < PARTS; part++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc_ntt[col][part][k] = 0.0;
+
+        const d2* bk_row = bk_ntt + (size_t)i * (R * K1 * PARTS) * (N / 2);
+#pragma unroll 1
+        for (int q = 0; q < K1; q++) {
+            uint32_t tw_[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t v = s_acc[q][src[k]];
+                tw_[k] = ((((v ^ neg[k]) - neg[k]) - s_acc[q][k * T + t]) + offset) ^ flip;
+            }
+#pragma unroll 1
+            for (int level = 0; level < L; level++) {  // rolled: keeps one transform's worth of code and registers live
+                const int r = q * L + level;
+                const d2* bk_poly = bk_row + (size_t)r * (K1 * PARTS) * (N / 2);
+                // Key row: column 0 is requested before the transform, every further column while
+                // the previous one is being multiplied, so that at most two columns are in flight.
+                d2 y[PARTS][4], ynext[PARTS][4];
+#pragma unroll
+                for (int part = 0; part < PARTS; part++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) y[part][kk] = bk_poly[(size_t)part * (N / 2) + kk * T + t];
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
+                W::template forward<true>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
+#pragma unroll
+                for (int col = 0; col < K1; col++) {
+                    if (col + 1 < K1) {
+#pragma unroll
+                        for (int part = 0; part < PARTS; part++)
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++)
+                                ynext[part][kk] = bk_poly[(size_t)((col + 1) * PARTS + part) * (N / 2) + kk * T + t];
+                    }
+#pragma unroll
+                    for (int part = 0; part < PARTS; part++)
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            acc_ntt[col][part][2 * kk] += mulmod_var(x[2 * kk], y[part][kk].x, p, pinv);
+                            acc_ntt[col][part][2 * kk + 1] += mulmod_var(x[2 * kk + 1], y[part][kk].y, p, pinv);
+                        }
+                    if (col + 1 < K1) {
+#pragma unroll
+                        for (int part = 0; part < PARTS; part++)
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) y[part][kk] = ynext[part][kk];
+                    }
+                }
+                // products are <= 1.41 p each: reduce after every third (running sum < 4.74 p)
+                if (r % 3 == 2 && r != R - 1) {
+#pragma unroll
+                    for (int col = 0; col < K1; col++)
+#pragma unroll
+                        for (int part = 0; part < PARTS; part++)
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                                acc_ntt[col][part][k] = reduce(acc_ntt[col][part][k], p, pinv);
+                }
+            }
+        }
+#pragma unroll
+        for (int col = 0; col < K1; col++) {
+            uint32_t delta[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) delta[k] = 0u;
+#pragma unroll
+            for (int part = 0; part < PARTS; part++) {
+                W::inverse(acc_ntt[col][part], u, table, s_tr, parity, t);
+#pragma unroll
+                for (int k = 0; k < 8; k++) delta[k] += to_torus(acc_ntt[col][part][k], p, pinv) << (part * shift);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) s_acc[col][k * T + t] += delta[k];
+        }
+        __syncthreads();
+    }
+
+    if (!extract) {
+        uint32_t* o = out + gate * (size_t)(K1 * N);
+        for (int e = t; e < K1 * N; e += T) o[e] = s_acc[e / N][e % N];
+        return;
+    }
+    uint32_t* o = out + gate * (size_t)(K * N + 1);
+    if (t == 0) o[0] = s_acc[0][0];
+    for (int e = t; e < K * N; e += T) {
+        const int qq = e / N, j = e - qq * N;
+        const uint32_t v = s_acc[1 + qq][j];
+        if (j == 0) o[1 + qq * N] = v;
+        else        o[1 + qq * N + (N - j)] = 0u - v;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+
+bool wg_has_kernel(int N, int K, int L, int bg) { return bg == 8 && N == 2048 && K == 1 && L == 3; }
+
+int wg_table_pairs(int N) { return N == 2048 ? WgNtt<11>::TABLE_PAIRS : 0; }
+
+// number of key parts and the split position for a parameter set: one part if the largest
+// accumulation (K+1) L N 2^(bg-1) 2^31 stays below p/2 with margin, else two halves of 16 bits
+void wg_split(int N, int K, int L, int bg, int* parts, int* shift) {
+    const double bound = (double)(K + 1) * L * N * (double)(1u << (bg - 1)) * 2147483648.0;
+    if (bound < 0.49 * 1711528530149377.0) { *parts = 1; *shift = 0; }
+    else { *parts = 2; *shift = 16; }
+}
+
+hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_polys,
+                                  int N, int parts, int shift, hipStream_t stream) {
+    if (N != 2048) return hipErrorInvalidValue;
+    bk_transform_wg_kernel<11><<<(unsigned)(n_polys * parts), WgNtt<11>::T, 0, stream>>>(u, table, bk, bk_ntt, parts,
+                                                                                         shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2* bk_ntt, const uint32_t* c,
+                                  const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L,
+                                  int parts, int shift, int extract, hipStream_t stream) {
+    if (n_gates == 0) return hipSuccess;
+    if (!(N == 2048 && K == 1 && L == 3 && parts == 2)) return hipErrorInvalidValue;
+    blind_rotate_wg_kernel<11, 1, 3, 2><<<(unsigned)n_gates, WgNtt<11>::T, 0, stream>>>(u, table, bk_ntt, c, tv, out, n,
+                                                                                         shift, extract);
+    return hipGetLastError();
+}
+
+}  // namespace tfhe_amd
