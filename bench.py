@@ -91,14 +91,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # TFHE_BENCH_BACKEND=gloo rehearses the multi-rank control flow on a box with fewer GPUs than
+    # ranks (ranks share devices, keys are broadcast as host tensors); the real run uses RCCL.
+    backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    bcast_dev = dev if backend == "nccl" else torch.device("cpu")
 
     p = tfhe_amd.params_default()
     n1, G = p.n + 1, args.gates_per_gpu
@@ -107,11 +115,11 @@ def main():
     bk_words, ks_words = int(np.prod(p.bk_shape())), int(np.prod(p.ks_shape()))
     if rank == 0:
         rs = np.random.RandomState(2026)
-        bk = torch.from_numpy(rs.randint(-2**31, 2**31, size=bk_words, dtype=np.int64).astype(np.int32)).to(dev)
-        ks = torch.from_numpy(rs.randint(-2**31, 2**31, size=ks_words, dtype=np.int64).astype(np.int32)).to(dev)
+        bk = torch.from_numpy(rs.randint(-2**31, 2**31, size=bk_words, dtype=np.int64).astype(np.int32)).to(bcast_dev)
+        ks = torch.from_numpy(rs.randint(-2**31, 2**31, size=ks_words, dtype=np.int64).astype(np.int32)).to(bcast_dev)
     else:
-        bk = torch.empty(bk_words, dtype=torch.int32, device=dev)
-        ks = torch.empty(ks_words, dtype=torch.int32, device=dev)
+        bk = torch.empty(bk_words, dtype=torch.int32, device=bcast_dev)
+        ks = torch.empty(ks_words, dtype=torch.int32, device=bcast_dev)
     t_bcast = 0.0
     if world > 1:
         torch.cuda.synchronize()
@@ -120,8 +128,9 @@ def main():
         dist.broadcast(ks, src=0)
         torch.cuda.synchronize()
         t_bcast = time.time() - t0
-    ctx = tfhe_amd.Context(p, bk, ks, device=local_rank, keys_on_device=True)
-    del bk
+    bk, ks = bk.to(dev), ks.to(dev)
+    ctx = tfhe_amd.Context(p, bk, ks, device=dev_index, keys_on_device=True)
+    del bk, ks
 
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
@@ -149,7 +158,7 @@ def main():
     barrier()
     br_ms, ks_ms, calls = ctx.timing()
     ctx.enable_timing(False)
-    el = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed_local], dtype=torch.float64, device=bcast_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
