@@ -7,12 +7,14 @@ Method names follow the reference's interface for this path: HomNAND::nand
 tensors on the GPU; the binding only passes their addresses.
 """
 import ctypes as C
+import os
 import pathlib
 
 import numpy as np
 
 _HERE = pathlib.Path(__file__).resolve().parent
-_LIB_FILE = _HERE / "libtfhe_amd.so"
+# TFHE_AMD_LIBRARY selects another build of the same library (kernel A/B measurements)
+_LIB_FILE = pathlib.Path(os.environ.get("TFHE_AMD_LIBRARY") or (_HERE / "libtfhe_amd.so"))
 _lib = None
 _load_error = None
 

@@ -263,6 +263,16 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw, c
     }
     const int q = r / L, level = r % L;
 
+    // Key row r of step i + 1 is requested at the top of step i: with one gate per workgroup the
+    // rows come from the Infinity Cache or HBM, and a full step hides that latency.
+    d2 y[K1][4], ynext[K1][4];
+    {
+        const d2* bk_poly = bk_ntt + (size_t)r * K1 * (kN / 2);
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) ynext[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+    }
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
         if ((i & 63) == 0) cvals = (i + lane < n) ? cg[1 + i + lane] : 0u;
@@ -270,12 +280,17 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw, c
         const int abar = (int)((ci + (1u << 21)) >> 22);
 
         // ---- phase 1: digit polynomial r -> NTT -> products with key row r ----
-        const d2* bk_poly = bk_ntt + ((size_t)i * R + r) * K1 * (kN / 2);
-        d2 y[K1][4];
 #pragma unroll
         for (int col = 0; col < K1; col++)
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) y[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+            for (int kk = 0; kk < 4; kk++) y[col][kk] = ynext[col][kk];
+        if (i + 1 < n) {
+            const d2* bk_poly = bk_ntt + ((size_t)(i + 1) * R + r) * K1 * (kN / 2);
+#pragma unroll
+            for (int col = 0; col < K1; col++)
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) ynext[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+        }
         double x[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {

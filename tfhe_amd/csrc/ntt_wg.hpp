@@ -43,6 +43,15 @@ struct WgNtt {
         return ((t >> b) << (b + 3)) | (k << b) | (t & ((1 << b) - 1));
     }
 
+    // Identity the optimiser cannot see through.  The twiddle rows are loop-invariant in a blind
+    // rotation; without this their loads are hoisted out of the step loop and every group's 28
+    // registers stay live for the whole kernel (168 registers, which costs the second workgroup
+    // per CU).
+    __device__ static __forceinline__ int opaque(int v) {
+        asm volatile("" : "+v"(v));
+        return v;
+    }
+
     // registers in layout `from` -> registers in layout `to`
     __device__ static __forceinline__ void transpose(double (&x)[8], double* buf, int from, int to, int t) {
 #pragma unroll
@@ -134,7 +143,7 @@ struct WgNtt {
             // the top of the transform
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
-            load_tw7(tw, table + 7 * (row_offset(g) + (t >> base(g))));
+            load_tw7(tw, table + 7 * (row_offset(g) + opaque(t >> base(g))));
             transpose(x, bufs + (parity & 1) * PAD, g - 1, g, t);
             parity++;
             constexpr bool kAlways = !SMALL;
@@ -158,7 +167,7 @@ struct WgNtt {
         for (int g = GROUPS - 1; g >= 1; g--) {
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
-            load_tw7(tw, inv_table + 7 * (row_offset(g) + (t >> base(g))));
+            load_tw7(tw, inv_table + 7 * (row_offset(g) + opaque(t >> base(g))));
 #pragma unroll
             for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
             if (g == GROUPS - 1) gs_group<LAST>(x, tw, p);

@@ -52,8 +52,12 @@ bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const u
 }
 
 // Transformed key layout: [n][R][K1][parts] polynomials (part innermost), each [4][T][2] doubles.
+// Two workgroups per CU (<= 256 registers per lane, 52 KB of LDS each): while one waits at a
+// transpose barrier the other one computes.  Measured alternatives: one workgroup per CU with
+// the L digit transforms of a polynomial interleaved in each wave (more parallelism per wave,
+// fewer barriers) is 20 % slower, three workgroups per CU spill and are 35 % slower.
 template <int LOGN, int K, int L, int PARTS>
-__global__ void __launch_bounds__(WgNtt<LOGN>::T)
+__global__ void __launch_bounds__(WgNtt<LOGN>::T, 2)
 blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d2* __restrict__ bk_ntt,
                        const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv, uint32_t* __restrict__ out,
                        int n, int shift, int extract) {
@@ -92,14 +96,6 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
     int parity = 0;
     for (int i = 0; i < n; i++) {
         const int abar = (int)((cg[1 + i] + (1u << (SH - 1))) >> SH);
-        int src[8];
-        uint32_t neg[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int sidx = (k * T + t - abar) & (2 * N - 1);
-            src[k] = sidx & (N - 1);
-            neg[k] = 0u - (uint32_t)((sidx >> LOGN) & 1);
-        }
 
         double acc_ntt[K1][PARTS][8];
 #pragma unroll
@@ -115,8 +111,10 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             uint32_t tw_[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const uint32_t v = s_acc[q][src[k]];
-                tw_[k] = ((((v ^ neg[k]) - neg[k]) - s_acc[q][k * T + t]) + offset) ^ flip;
+                const int sidx = (k * T + t - abar) & (2 * N - 1);
+                const uint32_t neg = 0u - (uint32_t)((sidx >> LOGN) & 1);
+                const uint32_t v = s_acc[q][sidx & (N - 1)];
+                tw_[k] = ((((v ^ neg) - neg) - s_acc[q][k * T + t]) + offset) ^ flip;
             }
 #pragma unroll 1
             for (int level = 0; level < L; level++) {  // rolled: keeps one transform's worth of code and registers live
@@ -124,36 +122,30 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                 const d2* bk_poly = bk_row + (size_t)r * (K1 * PARTS) * (N / 2);
                 // Key row: column 0 is requested before the transform, every further column while
                 // the previous one is being multiplied, so that at most two columns are in flight.
-                d2 y[PARTS][4], ynext[PARTS][4];
+                // Key row: K1 * PARTS tiles of 4 pairs per thread; tile 0 is requested before the
+                // transform, every further tile while the previous one is being multiplied.
+                d2 y[4], ynext[4];
 #pragma unroll
-                for (int part = 0; part < PARTS; part++)
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) y[part][kk] = bk_poly[(size_t)part * (N / 2) + kk * T + t];
+                for (int kk = 0; kk < 4; kk++) y[kk] = bk_poly[kk * T + t];
                 double x[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) x[k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
                 W::template forward<true>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
 #pragma unroll
-                for (int col = 0; col < K1; col++) {
-                    if (col + 1 < K1) {
+                for (int tile = 0; tile < K1 * PARTS; tile++) {
+                    const int col = tile / PARTS, part = tile % PARTS;
+                    if (tile + 1 < K1 * PARTS) {
 #pragma unroll
-                        for (int part = 0; part < PARTS; part++)
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++)
-                                ynext[part][kk] = bk_poly[(size_t)((col + 1) * PARTS + part) * (N / 2) + kk * T + t];
+                        for (int kk = 0; kk < 4; kk++) ynext[kk] = bk_poly[(size_t)(tile + 1) * (N / 2) + kk * T + t];
                     }
 #pragma unroll
-                    for (int part = 0; part < PARTS; part++)
+                    for (int kk = 0; kk < 4; kk++) {
+                        acc_ntt[col][part][2 * kk] += mulmod_var(x[2 * kk], y[kk].x, p, pinv);
+                        acc_ntt[col][part][2 * kk + 1] += mulmod_var(x[2 * kk + 1], y[kk].y, p, pinv);
+                    }
+                    if (tile + 1 < K1 * PARTS) {
 #pragma unroll
-                        for (int kk = 0; kk < 4; kk++) {
-                            acc_ntt[col][part][2 * kk] += mulmod_var(x[2 * kk], y[part][kk].x, p, pinv);
-                            acc_ntt[col][part][2 * kk + 1] += mulmod_var(x[2 * kk + 1], y[part][kk].y, p, pinv);
-                        }
-                    if (col + 1 < K1) {
-#pragma unroll
-                        for (int part = 0; part < PARTS; part++)
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) y[part][kk] = ynext[part][kk];
+                        for (int kk = 0; kk < 4; kk++) y[kk] = ynext[kk];
                     }
                 }
                 // products are <= 1.41 p each: reduce after every third (running sum < 4.74 p)
