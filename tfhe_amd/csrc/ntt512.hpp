@@ -131,6 +131,133 @@ __device__ __forceinline__ void gs8(double (&x)[8], const Tw7& t, double p) {
     for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], t.w[0], t.wp[0], p);
 }
 
+// ---- phase-ordered forms -------------------------------------------------------------------
+// A wave issues a dependent FP64 instruction only every ~9 cycles but independent ones every
+// ~5.5 (measured, tools/fp64_latency.hip), and the compiler emits each butterfly as one serial
+// chain.  These forms evaluate NB independent chains phase by phase and fence every phase with
+// a scheduling barrier, so that dependent instructions end up NB apart.
+__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
+
+template <int NB>
+__device__ __forceinline__ void mulmod_tw_n(double (&t)[NB], const double (&b)[NB], const double (&w)[NB],
+                                            const double (&wp)[NB], double p) {
+    double q[NB], h[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = b[i] * wp[i];
+#pragma unroll
+    for (int i = 0; i < NB; i++) h[i] = b[i] * w[i];
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = __builtin_rint(q[i]);
+#pragma unroll
+    for (int i = 0; i < NB; i++) t[i] = __builtin_fma(b[i], w[i], -h[i]);
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) h[i] = __builtin_fma(-q[i], p, h[i]);
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) t[i] = h[i] + t[i];
+    pin();
+}
+
+template <int NB>
+__device__ __forceinline__ void mulmod_var_n(double (&t)[NB], const double (&x)[NB], const double (&y)[NB], double p,
+                                             double pinv) {
+    double q[NB], h[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) h[i] = x[i] * y[i];
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = h[i] * pinv;
+#pragma unroll
+    for (int i = 0; i < NB; i++) t[i] = __builtin_fma(x[i], y[i], -h[i]);
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = __builtin_rint(q[i]);
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) h[i] = __builtin_fma(-q[i], p, h[i]);
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) t[i] = h[i] + t[i];
+    pin();
+}
+
+template <int NB>
+__device__ __forceinline__ void reduce_n(double (&x)[NB], double p, double pinv) {
+    double q[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = x[i] * pinv;
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) q[i] = __builtin_rint(q[i]);
+    pin();
+#pragma unroll
+    for (int i = 0; i < NB; i++) x[i] = __builtin_fma(-q[i], p, x[i]);
+    pin();
+}
+
+// Register pairs and twiddle slots of one radix-2 stage on the 8 registers of a lane.
+// D = 4, 2, 1 is the register distance; butterfly j in 0..3 pairs (lo(j), lo(j) + D) and uses
+// slot(j) of a Tw7-ordered twiddle array: [0] for D = 4, [1 + h] for D = 2, [3 + g] for D = 1.
+template <int D>
+__device__ __forceinline__ constexpr int stage_lo(int j) { return (j / D) * 2 * D + (j % D); }
+template <int D>
+__device__ __forceinline__ constexpr int stage_slot(int j) { return D == 4 ? 0 : (D == 2 ? 1 + j / 2 : 3 + j); }
+
+// one Cooley-Tukey stage (4 butterflies), phase-ordered
+template <int D, bool REDUCE_A>
+__device__ __forceinline__ void ct_stage_pinned(double (&x)[8], const double* w, const double* wp, double p,
+                                                double pinv) {
+    double a[4], b[4], ww[4], wwp[4], t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        a[j] = x[stage_lo<D>(j)];
+        b[j] = x[stage_lo<D>(j) + D];
+        ww[j] = w[stage_slot<D>(j)];
+        wwp[j] = wp[stage_slot<D>(j)];
+    }
+    if (REDUCE_A) reduce_n<4>(a, p, pinv);
+    mulmod_tw_n<4>(t, b, ww, wwp, p);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        x[stage_lo<D>(j) + D] = a[j] - t[j];
+        x[stage_lo<D>(j)] = a[j] + t[j];
+    }
+    pin();
+}
+
+// one Gentleman-Sande stage, phase-ordered
+template <int D>
+__device__ __forceinline__ void gs_stage_pinned(double (&x)[8], const double* w, const double* wp, double p) {
+    double d[4], ww[4], wwp[4], t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double lo = x[stage_lo<D>(j)], hi = x[stage_lo<D>(j) + D];
+        x[stage_lo<D>(j)] = lo + hi;
+        d[j] = lo - hi;
+        ww[j] = w[stage_slot<D>(j)];
+        wwp[j] = wp[stage_slot<D>(j)];
+    }
+    pin();
+    mulmod_tw_n<4>(t, d, ww, wwp, p);
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[stage_lo<D>(j) + D] = t[j];
+}
+
+template <bool REDUCE_A>
+__device__ __forceinline__ void ct8_pinned(double (&x)[8], const double* w, const double* wp, double p, double pinv) {
+    ct_stage_pinned<4, REDUCE_A>(x, w, wp, p, pinv);
+    ct_stage_pinned<2, false>(x, w, wp, p, pinv);
+    ct_stage_pinned<1, false>(x, w, wp, p, pinv);
+}
+
+__device__ __forceinline__ void gs8_pinned(double (&x)[8], const double* w, const double* wp, double p) {
+    gs_stage_pinned<1>(x, w, wp, p);
+    gs_stage_pinned<2>(x, w, wp, p);
+    gs_stage_pinned<4>(x, w, wp, p);
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS instructions of one wave execute in issue order; this only stops the compiler
     // from moving them across the exchange point.
@@ -182,10 +309,52 @@ __device__ __forceinline__ void transpose_b_to_a(double (&x)[8], double* tr, int
 // Growth between reductions, in units of p (a CT butterfly maps bound B to
 // B + 0.5 + 0.75 B / 5.26): after the layout-A stages <= 1.72, after layout B <= 4.29,
 // the distance-4 stage reduces its additive inputs, after layout C <= 3.2 < 5.26.
-template <bool SMALL, bool FINAL_REDUCE>
+template <bool SMALL, bool FINAL_REDUCE, bool PIN = false>
 __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform& u, const d2* s_tw,
                                                double* tr, int lane) {
     const double p = u.p, pinv = u.pinv;
+    if (PIN) {
+        // same arithmetic as below, butterflies issued phase by phase
+        if (SMALL) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double a = x[k], b = x[k + 4];
+                x[k] = __builtin_fma(b, u.zI, a);
+                x[k + 4] = __builtin_fma(-b, u.zI, a);
+            }
+            pin();
+            double b2[2], w2[2], wp2[2], t2[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double a = x[k], b = x[k + 2];
+                x[k] = __builtin_fma(b, u.z, a);
+                x[k + 2] = __builtin_fma(-b, u.z, a);
+                b2[k] = x[k + 6];
+                w2[k] = u.fw[3];
+                wp2[k] = u.fwp[3];
+            }
+            mulmod_tw_n<2>(t2, b2, w2, wp2, p);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double a = x[k + 4];
+                x[k + 6] = a - t2[k];
+                x[k + 4] = a + t2[k];
+            }
+            pin();
+            ct_stage_pinned<1, false>(x, u.fw + 1, u.fwp + 1, p, pinv);
+        } else {
+            ct8_pinned<false>(x, u.fw + 1, u.fwp + 1, p, pinv);
+        }
+        transpose_a_to_b(x, tr, lane);
+        Tw7 t;
+        load_tw7(t, s_tw + kTwFwdB + 7 * (lane >> 3));
+        ct8_pinned<false>(x, t.w, t.wp, p, pinv);
+        transpose_b_to_c(x, tr, lane);
+        load_tw7(t, s_tw + kTwFwdC + 7 * lane);
+        ct8_pinned<true>(x, t.w, t.wp, p, pinv);
+        if (FINAL_REDUCE) reduce_n<8>(x, p, pinv);
+        return;
+    }
     if (SMALL) {
         // distance 256, twiddle zeta^2 < 2^26: |x * zeta^2| < 2^33, no reduction needed
 #pragma unroll
@@ -232,10 +401,24 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform&
 // Inverse transform without the 1/N factor.  In: layout C, |x| < 2^53.  Out: layout A,
 // |x| <= 4 p.  Every group of three GS stages starts from |x| <= p/2 and doubles the bound
 // of the sum outputs at most three times.
+template <bool PIN = false>
 __device__ __forceinline__ void ntt512_inverse(double (&x)[8], const NttUniform& u, const d2* s_tw,
                                                double* tr, int lane) {
     const double p = u.p, pinv = u.pinv;
     Tw7 t;
+    if (PIN) {
+        reduce_n<8>(x, p, pinv);
+        load_tw7(t, s_tw + kTwInvC + 7 * lane);
+        gs8_pinned(x, t.w, t.wp, p);
+        transpose_c_to_b(x, tr, lane);
+        reduce_n<8>(x, p, pinv);
+        load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
+        gs8_pinned(x, t.w, t.wp, p);
+        transpose_b_to_a(x, tr, lane);
+        reduce_n<8>(x, p, pinv);
+        gs8_pinned(x, u.iw + 1, u.iwp + 1, p);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
     load_tw7(t, s_tw + kTwInvC + 7 * lane);
