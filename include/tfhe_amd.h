@@ -89,6 +89,50 @@ int tfhe_amd_nand_batch(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b,
 int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
                                size_t n_gates, void* stream);
 
+/* The other two-input gates.  The reference has NAND only; each gate below is the same bootstrap
+ * and key switch behind another linear pre-combination, c = (offset, 0, ..) + sa*a + sb*b, of which
+ * reference src/hom_nand.hpp:76-78 is the NAND instance (true = +1/8, false = -1/8, reference
+ * src/types.hpp:25,34).  ANDNY = (not a) and b, ANDYN = a and (not b), likewise ORNY / ORYN. */
+enum {
+    TFHE_AMD_GATE_NAND = 0, /* ( 1/8) - a - b */
+    TFHE_AMD_GATE_AND = 1,  /* (-1/8) + a + b */
+    TFHE_AMD_GATE_OR = 2,   /* ( 1/8) + a + b */
+    TFHE_AMD_GATE_NOR = 3,  /* (-1/8) - a - b */
+    TFHE_AMD_GATE_XOR = 4,  /* ( 1/4) + 2(a + b) */
+    TFHE_AMD_GATE_XNOR = 5, /* (-1/4) - 2(a + b) */
+    TFHE_AMD_GATE_ANDNY = 6,
+    TFHE_AMD_GATE_ANDYN = 7,
+    TFHE_AMD_GATE_ORNY = 8,
+    TFHE_AMD_GATE_ORYN = 9,
+    TFHE_AMD_GATE_COUNT = 10
+};
+/* out[g] = op(a[g], b[g]); same layouts and memory rules as tfhe_amd_nand_batch[_device]. */
+int tfhe_amd_gate_batch(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                        size_t n_gates);
+int tfhe_amd_gate_batch_device(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                               size_t n_gates, void* stream);
+/* One gate code per gate: ops [n_gates] bytes in DEVICE memory (a dependency level of a circuit with
+ * mixed gate types in one call).  A code outside the enum evaluates as NAND. */
+int tfhe_amd_gates_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uint32_t* a, const uint32_t* b,
+                                uint32_t* out, size_t n_gates, void* stream);
+/* out[g] = not a[g] = -a[g]; no bootstrap, noise unchanged. */
+int tfhe_amd_not_batch(tfhe_amd_ctx* ctx, const uint32_t* a, uint32_t* out, size_t n_gates);
+int tfhe_amd_not_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, uint32_t* out, size_t n_gates, void* stream);
+/* out[g] = sel[g] ? x1[g] : x0[g]: the lv1 results of AND(sel, x1) and ANDNY(sel, x0) are added,
+ * plus (1/8, 0, ..), and key-switched once: two blind rotations, one key switch per gate. */
+int tfhe_amd_mux_batch(tfhe_amd_ctx* ctx, const uint32_t* sel, const uint32_t* x1, const uint32_t* x0, uint32_t* out,
+                       size_t n_gates);
+int tfhe_amd_mux_batch_device(tfhe_amd_ctx* ctx, const uint32_t* sel, const uint32_t* x1, const uint32_t* x0,
+                              uint32_t* out, size_t n_gates, void* stream);
+
+/* One dependency level of a circuit in one call: gates [0, n_gates - n_mux) are two-input gates
+ * with codes ops[g] on rows a[g], b[g]; the last n_mux gates are MUXes with sel = a[g], x1 = b[g]
+ * and x0 = x0[g - (n_gates - n_mux)] (x0: [n_mux][n+1]).  All n_gates + n_mux blind rotations run
+ * in one launch, so a level costs one blind-rotation latency whatever its mix.  ops: device
+ * memory, [n_gates - n_mux] bytes (may be NULL when every gate is a MUX). */
+int tfhe_amd_level_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uint32_t* a, const uint32_t* b,
+                                const uint32_t* x0, uint32_t* out, size_t n_gates, size_t n_mux, void* stream);
+
 /* gate_bootstrapping_tlwe_to_tlwe followed by identity_key_switch on pre-combined inputs
  * (reference src/hom_nand.hpp:79-80): out[g] = KS(bootstrap(c[g])).  The building block
  * of every other two-input gate. */

@@ -183,6 +183,22 @@ def nand_combine(a, b, p):
     return out
 
 
+GATES = {"nand": 0, "and": 1, "or": 2, "nor": 3, "xor": 4, "xnor": 5, "andny": 6, "andyn": 7, "orny": 8, "oryn": 9}
+GATE_TRUTH = {"nand": lambda a, b: 1 - (a & b), "and": lambda a, b: a & b, "or": lambda a, b: a | b,
+              "nor": lambda a, b: 1 - (a | b), "xor": lambda a, b: a ^ b, "xnor": lambda a, b: 1 - (a ^ b),
+              "andny": lambda a, b: (1 - a) & b, "andyn": lambda a, b: a & (1 - b),
+              "orny": lambda a, b: (1 - a) | b, "oryn": lambda a, b: a | (1 - b)}
+
+
+def gate_combine(op, a, b, p):
+    a, b = _u32(a), _u32(b)
+    out = np.empty(p.n + 1, dtype=np.uint32)
+    rc = lib().tfo_gate_combine(_p(out), C.c_int(GATES[op] if isinstance(op, str) else int(op)), _p(a), _p(b), C.byref(p))
+    if rc:
+        raise ValueError(f"unknown gate {op}")
+    return out
+
+
 def nand(a, b, bk, ks, p, mode):
     a, b, bk, ks = _u32(a), _u32(b), _u32(bk), _u32(ks)
     out = np.empty(p.n + 1, dtype=np.uint32)
@@ -217,6 +233,29 @@ class Context:
         a, b = _u32(a), _u32(b)
         out = np.empty_like(a)
         lib().tfo_ctx_nand_batch(self.h, _p(out), _p(a), _p(b), C.c_size_t(a.shape[0]), C.c_int(threads))
+        return out
+
+    def gate_batch(self, op, a, b, threads=0):
+        """op: a gate name / code for all gates, or a uint8 array of codes, one per gate."""
+        a, b = _u32(a), _u32(b)
+        out = np.empty_like(a)
+        ops = None
+        code = 0
+        if isinstance(op, np.ndarray):
+            ops = np.ascontiguousarray(op, dtype=np.uint8)
+            assert ops.shape[0] == a.shape[0]
+        else:
+            code = GATES[op] if isinstance(op, str) else int(op)
+        rc = lib().tfo_ctx_gate_batch(self.h, C.c_int(code), _p(ops) if ops is not None else None, _p(out), _p(a),
+                                      _p(b), C.c_size_t(a.shape[0]), C.c_int(threads))
+        if rc:
+            raise ValueError("unknown gate code")
+        return out
+
+    def mux_batch(self, sel, x1, x0, threads=0):
+        sel, x1, x0 = _u32(sel), _u32(x1), _u32(x0)
+        out = np.empty_like(sel)
+        lib().tfo_ctx_mux_batch(self.h, _p(out), _p(sel), _p(x1), _p(x0), C.c_size_t(sel.shape[0]), C.c_int(threads))
         return out
 
     def bootstrap_batch(self, c, threads=0):

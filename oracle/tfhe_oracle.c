@@ -348,6 +348,37 @@ void tfo_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, const t
     for (int j = 1; j <= p->n; j++) c[j] = 0u - (a[j] + b[j]);
 }
 
+/* Generalisation of the line above to the other two-input gates (the reference has none). */
+int tfo_gate_coefficients(int op, uint32_t* offset, int32_t* sa, int32_t* sb) {
+    const uint32_t mu = 1u << 29, q = 1u << 30;
+    switch (op) {
+    case TFO_NAND:  *offset = mu;      *sa = -1; *sb = -1; return 0;
+    case TFO_AND:   *offset = 0u - mu; *sa = 1;  *sb = 1;  return 0;
+    case TFO_OR:    *offset = mu;      *sa = 1;  *sb = 1;  return 0;
+    case TFO_NOR:   *offset = 0u - mu; *sa = -1; *sb = -1; return 0;
+    case TFO_XOR:   *offset = q;       *sa = 2;  *sb = 2;  return 0;
+    case TFO_XNOR:  *offset = 0u - q;  *sa = -2; *sb = -2; return 0;
+    case TFO_ANDNY: *offset = 0u - mu; *sa = -1; *sb = 1;  return 0;
+    case TFO_ANDYN: *offset = 0u - mu; *sa = 1;  *sb = -1; return 0;
+    case TFO_ORNY:  *offset = mu;      *sa = -1; *sb = 1;  return 0;
+    case TFO_ORYN:  *offset = mu;      *sa = 1;  *sb = -1; return 0;
+    default: return -1;
+    }
+}
+
+int tfo_gate_combine(uint32_t* c, int op, const uint32_t* a, const uint32_t* b, const tfo_params* p) {
+    uint32_t off;
+    int32_t sa, sb;
+    if (tfo_gate_coefficients(op, &off, &sa, &sb)) return -1;
+    for (int j = 0; j <= p->n; j++) c[j] = (uint32_t)sa * a[j] + (uint32_t)sb * b[j];
+    c[0] += off;
+    return 0;
+}
+
+void tfo_not(uint32_t* out, const uint32_t* a, const tfo_params* p) {
+    for (int j = 0; j <= p->n; j++) out[j] = 0u - a[j];
+}
+
 /* reference src/hom_nand.hpp:74-81 */
 void tfo_nand(uint32_t* out, const uint32_t* a, const uint32_t* b, const uint32_t* bk, const uint32_t* ks,
               const tfo_params* p, int mode) {
@@ -482,6 +513,54 @@ void tfo_ctx_nand_batch(const tfo_ctx* ctx, uint32_t* out, const uint32_t* a, co
         uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * n1);
         tfo_nand_combine(c, a + (size_t)g * n1, b + (size_t)g * n1, &ctx->p);
         tfo_ctx_bootstrap(ctx, out + (size_t)g * n1, c);
+        free(c);
+    }
+}
+
+int tfo_ctx_gate_batch(const tfo_ctx* ctx, int op, const uint8_t* ops, uint32_t* out, const uint32_t* a,
+                       const uint32_t* b, size_t n_gates, int threads) {
+    const size_t n1 = (size_t)ctx->p.n + 1;
+    uint32_t off;
+    int32_t sa, sb;
+    for (size_t g = 0; g < n_gates; g++)
+        if (tfo_gate_coefficients(ops ? ops[g] : op, &off, &sa, &sb)) return -1;
+    if (threads <= 0) threads = tfo_max_threads();
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (long g = 0; g < (long)n_gates; g++) {
+        uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * n1);
+        tfo_gate_combine(c, ops ? ops[g] : op, a + (size_t)g * n1, b + (size_t)g * n1, &ctx->p);
+        tfo_ctx_bootstrap(ctx, out + (size_t)g * n1, c);
+        free(c);
+    }
+    return 0;
+}
+
+void tfo_ctx_mux_batch(const tfo_ctx* ctx, uint32_t* out, const uint32_t* sel, const uint32_t* x1,
+                       const uint32_t* x0, size_t n_gates, int threads) {
+    const tfo_params* p = &ctx->p;
+    const size_t n1 = (size_t)p->n + 1, W = (size_t)(p->K + 1) * p->N, L1 = (size_t)p->N * p->K + 1;
+    if (threads <= 0) threads = tfo_max_threads();
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (long g = 0; g < (long)n_gates; g++) {
+        uint32_t* c = (uint32_t*)malloc(sizeof(uint32_t) * (n1 + W + 2 * L1));
+        uint32_t* acc = c + n1;
+        uint32_t* u1 = acc + W;
+        uint32_t* u0 = u1 + L1;
+        tfo_gate_combine(c, TFO_AND, sel + (size_t)g * n1, x1 + (size_t)g * n1, p);
+        tfo_ctx_blind_rotate(ctx, acc, c);
+        tfo_sample_extract_index(u1, acc, 0, p);
+        tfo_gate_combine(c, TFO_ANDNY, sel + (size_t)g * n1, x0 + (size_t)g * n1, p);
+        tfo_ctx_blind_rotate(ctx, acc, c);
+        tfo_sample_extract_index(u0, acc, 0, p);
+        for (size_t j = 0; j < L1; j++) u1[j] += u0[j];
+        u1[0] += 1u << 29;
+        tfo_identity_key_switch(out + (size_t)g * n1, u1, ctx->ks, p);
         free(c);
     }
 }

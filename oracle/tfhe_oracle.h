@@ -77,6 +77,17 @@ void tfo_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, const t
 void tfo_nand(uint32_t* out, const uint32_t* a, const uint32_t* b, const uint32_t* bk, const uint32_t* ks,
               const tfo_params* p, int mode);
 
+/* Two-input gates other than NAND.  The reference has NAND only; every other gate is the same
+ * bootstrap and key switch behind another linear pre-combination (reference src/hom_nand.hpp:76-78
+ * is the NAND instance): c = (offset, 0, ..) + sa * a + sb * b with true = +1/8, false = -1/8
+ * (reference src/types.hpp:25,34).  Gate codes as in include/tfhe_amd.h. */
+enum { TFO_NAND = 0, TFO_AND, TFO_OR, TFO_NOR, TFO_XOR, TFO_XNOR, TFO_ANDNY, TFO_ANDYN, TFO_ORNY, TFO_ORYN,
+       TFO_GATE_COUNT };
+/* returns 0 and fills offset / sa / sb, or -1 for an unknown code */
+int tfo_gate_coefficients(int op, uint32_t* offset, int32_t* sa, int32_t* sb);
+int tfo_gate_combine(uint32_t* c, int op, const uint32_t* a, const uint32_t* b, const tfo_params* p);
+void tfo_not(uint32_t* out, const uint32_t* a, const tfo_params* p);
+
 /* ---- evaluation context with the bootstrapping key pre-transformed (NTT mode only) ---- */
 typedef struct tfo_ctx tfo_ctx;
 tfo_ctx* tfo_ctx_create(const tfo_params* p, const uint32_t* bk, const uint32_t* ks);
@@ -88,6 +99,13 @@ void tfo_ctx_nand_batch(const tfo_ctx* ctx, uint32_t* out, const uint32_t* a, co
                         size_t n_gates, int threads);
 /* out[g] = keyswitch(bootstrap(c[g])) on pre-combined inputs */
 void tfo_ctx_bootstrap_batch(const tfo_ctx* ctx, uint32_t* out, const uint32_t* c, size_t n_gates, int threads);
+/* out[g] = gate ops[g] (or `op` for all when ops == NULL) of a[g], b[g] */
+int tfo_ctx_gate_batch(const tfo_ctx* ctx, int op, const uint8_t* ops, uint32_t* out, const uint32_t* a,
+                       const uint32_t* b, size_t n_gates, int threads);
+/* out[g] = sel[g] ? x1[g] : x0[g]: two bootstraps without key switch (AND(sel, x1), ANDNY(sel, x0)),
+ * their lv1 sum plus (1/8, 0, ..), one key switch */
+void tfo_ctx_mux_batch(const tfo_ctx* ctx, uint32_t* out, const uint32_t* sel, const uint32_t* x1,
+                       const uint32_t* x0, size_t n_gates, int threads);
 int tfo_max_threads(void);
 
 /* ---- seeded client side: key generation, encryption, decryption ---- */

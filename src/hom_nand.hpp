@@ -1,6 +1,8 @@
 // Drop-in for KowerKoint/TFHE's src/hom_nand.hpp: the gate API.  Key generation, encryption and
 // decryption run on the host; nand() is evaluated on the GPU through libtfhe_amd, and
-// nand_batch() (not in the reference) evaluates many independent gates in one call.
+// nand_batch() (not in the reference) evaluates many independent gates in one call.  gate(),
+// gate_batch(), hom_not() and mux() (not in the reference either) are the other gates: the same
+// bootstrap behind another linear combination of the operands.
 //
 // Unlike the reference (src/hom_nand.hpp:26,49) the TRGSW member honours TRLWEParameter, so the
 // class can be instantiated with a non-default ring.
@@ -107,6 +109,47 @@ public:
         res.reserve(G);
         for (size_t g = 0; g < G; g++) res.push_back(gpu::take_vector<N_LV0 + 1>(out.data() + g * W));
         return res;
+    }
+
+    // Gate codes of the C ABI (TFHE_AMD_GATE_*): ANDNY = (not a) and b, ANDYN = a and (not b).
+    enum class Gate { NAND = 0, AND, OR, NOR, XOR, XNOR, ANDNY, ANDYN, ORNY, ORYN };
+
+    Cipher gate(Gate op, const Cipher& a, const Cipher& b, const EvaluateKey& evaluate_key) {
+        std::vector<uint32_t> fa, fb, out((size_t)N_LV0 + 1);
+        gpu::put(fa, a);
+        gpu::put(fb, b);
+        gpu::check(tfhe_amd_gate_batch(context(evaluate_key), (int)op, fa.data(), fb.data(), out.data(), 1), "gate");
+        return gpu::take_vector<N_LV0 + 1>(out.data());
+    }
+
+    std::vector<Cipher> gate_batch(Gate op, const std::vector<Cipher>& a, const std::vector<Cipher>& b,
+                                   const EvaluateKey& evaluate_key) {
+        if (a.size() != b.size()) throw std::invalid_argument("gate_batch: a and b differ in length");
+        const size_t G = a.size(), W = (size_t)N_LV0 + 1;
+        std::vector<uint32_t> fa, fb, out(G * W);
+        for (size_t g = 0; g < G; g++) {
+            gpu::put(fa, a[g]);
+            gpu::put(fb, b[g]);
+        }
+        gpu::check(tfhe_amd_gate_batch(context(evaluate_key), (int)op, fa.data(), fb.data(), out.data(), G),
+                   "gate_batch");
+        std::vector<Cipher> res;
+        res.reserve(G);
+        for (size_t g = 0; g < G; g++) res.push_back(gpu::take_vector<N_LV0 + 1>(out.data() + g * W));
+        return res;
+    }
+
+    // -a: no bootstrap, host arithmetic
+    Cipher hom_not(const Cipher& a) { return -a; }
+
+    // sel ? x1 : x0 (two blind rotations, one key switch)
+    Cipher mux(const Cipher& sel, const Cipher& x1, const Cipher& x0, const EvaluateKey& evaluate_key) {
+        std::vector<uint32_t> fs, f1, f0, out((size_t)N_LV0 + 1);
+        gpu::put(fs, sel);
+        gpu::put(f1, x1);
+        gpu::put(f0, x0);
+        gpu::check(tfhe_amd_mux_batch(context(evaluate_key), fs.data(), f1.data(), f0.data(), out.data(), 1), "mux");
+        return gpu::take_vector<N_LV0 + 1>(out.data());
     }
 };
 }  // namespace TFHE

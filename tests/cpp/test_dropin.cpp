@@ -222,6 +222,33 @@ static void test_hom_nand() {  // reference test/main.cpp:180-224: 50 chained ga
     }
 }
 
+static void test_other_gates() {  // not in the reference: truth tables of the other gates and MUX
+    using H = HomNAND<>;
+    H h(77);
+    auto sk = h.generate_secret_key();
+    auto ek = h.make_evaluate_key(sk);
+    struct { H::Gate g; bool tt[4]; } table[] = {
+        {H::Gate::NAND, {1, 1, 1, 0}}, {H::Gate::AND, {0, 0, 0, 1}},  {H::Gate::OR, {0, 1, 1, 1}},
+        {H::Gate::NOR, {1, 0, 0, 0}},  {H::Gate::XOR, {0, 1, 1, 0}},  {H::Gate::XNOR, {1, 0, 0, 1}},
+        {H::Gate::ANDNY, {0, 1, 0, 0}}, {H::Gate::ANDYN, {0, 0, 1, 0}}, {H::Gate::ORNY, {1, 1, 0, 1}},
+        {H::Gate::ORYN, {1, 0, 1, 1}}};
+    for (auto& row : table) {
+        std::vector<H::Cipher> va, vb;
+        for (int t = 0; t < 4; t++) {  // t = 2a + b
+            va.push_back(h.encrypt(t >> 1, sk));
+            vb.push_back(h.encrypt(t & 1, sk));
+        }
+        auto out = h.gate_batch(row.g, va, vb, ek);
+        for (int t = 0; t < 4; t++) CHECK(h.decrypt(out[t], sk) == row.tt[t]);
+        CHECK(h.gate(row.g, va[2], vb[2], ek) == out[2]);
+    }
+    for (int t = 0; t < 8; t++) {
+        const bool s = t & 4, x1 = t & 2, x0 = t & 1;
+        CHECK(h.decrypt(h.mux(h.encrypt(s, sk), h.encrypt(x1, sk), h.encrypt(x0, sk), ek), sk) == (s ? x1 : x0));
+        CHECK(h.decrypt(h.hom_not(h.encrypt(s, sk)), sk) == !s);
+    }
+}
+
 struct RingN1024 { constexpr static int N = 1024; constexpr static int K = 1; constexpr static double ALPHA = 2.9802322387695312e-08; };
 struct Lv1N1024 { constexpr static int N = 1024; constexpr static double ALPHA = 2.9802322387695312e-08; };
 struct Gsw1024 { constexpr static int K = 1; constexpr static int BG_BIT = 8; constexpr static int L = 3; };
@@ -244,6 +271,7 @@ static void run_gpu() {
     test_bootstrapping();
     test_key_switching();
     test_hom_nand();
+    test_other_gates();
     test_hom_nand_other_ring();
     std::puts("gpu group ok");
 }

@@ -165,3 +165,92 @@ def test_config4_ripple_carry_adder(keys, ctx, octx):
         if check_wires:
             C.evaluate(gates, w, lambda u, v: octx.nand_batch(u, v), levels)
             assert np.array_equal(got, w)
+
+
+# ---- gates other than NAND (the reference has none: parity is against the oracle, semantics by
+# ---- decryption) -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("op", sorted(O.GATES))
+def test_gate_bit_exact_and_truth_table(keys, ctx, octx, op):
+    p, s0, _, _, _ = keys
+    abits = np.array([0, 0, 1, 1, 1, 0])
+    bbits = np.array([0, 1, 0, 1, 0, 0])
+    r = O.rng(100 + O.GATES[op])
+    a, b = O.encrypt_bits(abits, s0, p, r), O.encrypt_bits(bbits, s0, p, r)
+    got = ctx.gate(op, a, b)
+    assert np.array_equal(got, octx.gate_batch(op, a, b))
+    assert np.array_equal(O.decrypt_bits(got, s0, p), O.GATE_TRUTH[op](abits, bbits))
+
+
+def test_per_gate_codes_not_and_mux_device(keys, ctx, octx):
+    import torch
+
+    p, s0, _, _, _ = keys
+    n = 24
+    rs = np.random.RandomState(5)
+    r = O.rng(55)
+    bits = rs.randint(0, 2, (3, n))
+    a, b, c = (O.encrypt_bits(bits[i], s0, p, r) for i in range(3))
+    ops = rs.randint(0, 10, n).astype(np.uint8)
+    da, db, dc = (torch.from_numpy(x.view(np.int32)).cuda() for x in (a, b, c))
+    out = torch.empty_like(da)
+    ctx.gate_device(torch.from_numpy(ops).cuda(), da, db, out)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), octx.gate_batch(ops, a, b))
+    ctx.mux_device(da, db, dc, out)
+    ctx.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, octx.mux_batch(a, b, c))
+    assert np.array_equal(O.decrypt_bits(got, s0, p), np.where(bits[0] == 1, bits[1], bits[2]))
+    assert np.array_equal(ctx.mux(a, b, c), got)
+    ctx.not_device(da, out)
+    ctx.synchronize()
+    assert np.array_equal(O.decrypt_bits(out.cpu().numpy().view(np.uint32), s0, p), 1 - bits[0])
+    assert np.array_equal(ctx.not_(a), out.cpu().numpy().view(np.uint32))
+
+
+def test_unknown_gate_code_is_an_error(keys, ctx):
+    import tfhe_amd
+
+    p = keys[0]
+    z = np.zeros((1, p.n + 1), dtype=np.uint32)
+    with pytest.raises(tfhe_amd.TfheAmdError):
+        ctx.gate(10, z, z)
+    with pytest.raises(ValueError):
+        ctx.gate("frob", z, z)
+
+
+def test_mux_adder_32_bits_on_device(keys, ctx, octx):
+    """32-bit adder with XOR and MUX gates, every level one batched device call; ciphertexts equal
+    to the oracle run in the same level order, sum correct after decryption."""
+    import torch
+    from tfhe_amd import circuit as C
+
+    p, s0, _, _, _ = keys
+    bits = 32
+    gates, n_wires, a, b, zero, sums, cout = C.mux_adder(bits)
+    levels = C.levelize(gates, n_wires)
+    rs = np.random.RandomState(3)
+    x, y = int(rs.randint(0, 2**32, dtype=np.uint64)), int(rs.randint(0, 2**32, dtype=np.uint64))
+    r = O.rng(33)
+    w = np.zeros((n_wires, p.n + 1), dtype=np.uint32)
+    w[a] = O.encrypt_bits([(x >> i) & 1 for i in range(bits)], s0, p, r)
+    w[b] = O.encrypt_bits([(y >> i) & 1 for i in range(bits)], s0, p, r)
+    w[zero] = C.trivial_bit(0, p.n + 1)
+    dw = torch.from_numpy(w.view(np.int32).copy()).cuda()
+    C.evaluate(gates, dw, C.DeviceBackend(ctx), levels)
+    torch.cuda.synchronize()
+    got = dw.cpu().numpy().view(np.uint32)
+
+    class OracleBackend:
+        def gates(self, ops, u, v):
+            return octx.gate_batch(np.asarray(ops, dtype=np.uint8), u, v)
+
+        def mux(self, s, x1, x0):
+            return octx.mux_batch(s, x1, x0)
+
+    C.evaluate(gates, w, OracleBackend(), levels)
+    assert np.array_equal(got, w)
+    total = sum(int(v) << i for i, v in enumerate(O.decrypt_bits(got[sums], s0, p)))
+    total += int(O.decrypt_bits(got[[cout]], s0, p)[0]) << bits
+    assert total == x + y

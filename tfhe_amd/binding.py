@@ -88,6 +88,14 @@ def library():
     lib.tfhe_amd_ctx_destroy.restype = None
     lib.tfhe_amd_nand_batch.argtypes = [vp, vp, vp, vp, sz]
     lib.tfhe_amd_nand_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.tfhe_amd_gate_batch.argtypes = [vp, i32, vp, vp, vp, sz]
+    lib.tfhe_amd_gate_batch_device.argtypes = [vp, i32, vp, vp, vp, sz, vp]
+    lib.tfhe_amd_gates_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.tfhe_amd_level_batch_device.argtypes = [vp, vp, vp, vp, vp, vp, sz, sz, vp]
+    lib.tfhe_amd_not_batch.argtypes = [vp, vp, vp, sz]
+    lib.tfhe_amd_not_batch_device.argtypes = [vp, vp, vp, sz, vp]
+    lib.tfhe_amd_mux_batch.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.tfhe_amd_mux_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, vp]
     lib.tfhe_amd_bootstrap_batch.argtypes = [vp, vp, vp, sz]
     lib.tfhe_amd_bootstrap_batch_device.argtypes = [vp, vp, vp, sz, vp]
     lib.tfhe_amd_gate_bootstrapping_batch.argtypes = [vp, vp, vp, sz]
@@ -134,6 +142,18 @@ def _dev_ptr(t, words):
     if not (t.is_cuda and t.is_contiguous() and t.element_size() == 4 and t.numel() == words):
         raise ValueError("expected a contiguous 32-bit GPU tensor of %d elements" % words)
     return C.c_void_p(t.data_ptr())
+
+
+# Gate codes of the C ABI (TFHE_AMD_GATE_*).  ANDNY = (not a) and b, ANDYN = a and (not b).
+GATES = {"nand": 0, "and": 1, "or": 2, "nor": 3, "xor": 4, "xnor": 5, "andny": 6, "andyn": 7, "orny": 8, "oryn": 9}
+
+
+def gate_code(op):
+    if isinstance(op, str):
+        if op not in GATES:
+            raise ValueError(f"unknown gate {op!r}")
+        return GATES[op]
+    return int(op)
 
 
 class Context:
@@ -198,6 +218,38 @@ class Context:
                                              out.ctypes.data_as(C.c_void_p), a.shape[0]))
         return out
 
+    def gate(self, op, a, b):
+        """out[g] = op(a[g], b[g]) for a gate name or code: the bootstrap of NAND behind another
+        linear combination (the reference has NAND only, src/hom_nand.hpp:76-78)."""
+        a, b = _host_u32(a), _host_u32(b)
+        if a.shape != b.shape or a.ndim != 2 or a.shape[1] != self.params.n1:
+            raise ValueError("a and b must both be [G, n+1]")
+        out = np.empty_like(a)
+        _check(library().tfhe_amd_gate_batch(self._h, gate_code(op), a.ctypes.data_as(C.c_void_p),
+                                             b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.shape[0]))
+        return out
+
+    def not_(self, a):
+        """out[g] = -a[g]: homomorphic NOT, no bootstrap."""
+        a = _host_u32(a)
+        if a.ndim != 2 or a.shape[1] != self.params.n1:
+            raise ValueError("a must be [G, n+1]")
+        out = np.empty_like(a)
+        _check(library().tfhe_amd_not_batch(self._h, a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                            a.shape[0]))
+        return out
+
+    def mux(self, sel, x1, x0):
+        """out[g] = sel[g] ? x1[g] : x0[g] (two blind rotations, one key switch per gate)."""
+        sel, x1, x0 = _host_u32(sel), _host_u32(x1), _host_u32(x0)
+        if not (sel.shape == x1.shape == x0.shape) or sel.ndim != 2 or sel.shape[1] != self.params.n1:
+            raise ValueError("sel, x1 and x0 must all be [G, n+1]")
+        out = np.empty_like(sel)
+        _check(library().tfhe_amd_mux_batch(self._h, sel.ctypes.data_as(C.c_void_p), x1.ctypes.data_as(C.c_void_p),
+                                            x0.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                            sel.shape[0]))
+        return out
+
     def bootstrap(self, c):
         """out[g] = identity_key_switch(gate_bootstrapping_tlwe_to_tlwe(c[g])) (reference src/hom_nand.hpp:79-80)."""
         c = _host_u32(c)
@@ -250,6 +302,50 @@ class Context:
         w = g * self.params.n1
         _check(library().tfhe_amd_nand_batch_device(self._h, _dev_ptr(a, w), _dev_ptr(b, w), _dev_ptr(out, w), g,
                                                     self._stream_ptr(stream)))
+        return out
+
+    def gate_device(self, op, a, b, out, stream=None):
+        """op: a gate name or code for the whole batch, or a uint8 GPU tensor of codes, one per gate."""
+        g = a.shape[0]
+        w = g * self.params.n1
+        if hasattr(op, "data_ptr"):
+            if not (op.is_cuda and op.is_contiguous() and op.element_size() == 1 and op.numel() == g):
+                raise ValueError("per-gate codes must be a contiguous uint8 GPU tensor of %d elements" % g)
+            _check(library().tfhe_amd_gates_batch_device(self._h, C.c_void_p(op.data_ptr()), _dev_ptr(a, w),
+                                                         _dev_ptr(b, w), _dev_ptr(out, w), g, self._stream_ptr(stream)))
+        else:
+            _check(library().tfhe_amd_gate_batch_device(self._h, gate_code(op), _dev_ptr(a, w), _dev_ptr(b, w),
+                                                        _dev_ptr(out, w), g, self._stream_ptr(stream)))
+        return out
+
+    def level_device(self, ops, a, b, x0, out, n_mux, stream=None):
+        """One dependency level: two-input gates with per-gate codes `ops` (uint8 GPU tensor,
+        [G - n_mux]) first, then n_mux MUX gates (sel = a row, x1 = b row, x0 rows in `x0`,
+        [n_mux, n+1]); all blind rotations in one launch."""
+        g = a.shape[0]
+        w = g * self.params.n1
+        n_two = g - n_mux
+        if n_two and not (ops is not None and ops.is_cuda and ops.is_contiguous() and ops.element_size() == 1
+                          and ops.numel() == n_two):
+            raise ValueError("ops must be a contiguous uint8 GPU tensor of %d elements" % n_two)
+        _check(library().tfhe_amd_level_batch_device(
+            self._h, C.c_void_p(ops.data_ptr()) if n_two else None, _dev_ptr(a, w), _dev_ptr(b, w),
+            _dev_ptr(x0, n_mux * self.params.n1) if n_mux else None, _dev_ptr(out, w), g, n_mux,
+            self._stream_ptr(stream)))
+        return out
+
+    def not_device(self, a, out, stream=None):
+        g = a.shape[0]
+        w = g * self.params.n1
+        _check(library().tfhe_amd_not_batch_device(self._h, _dev_ptr(a, w), _dev_ptr(out, w), g,
+                                                   self._stream_ptr(stream)))
+        return out
+
+    def mux_device(self, sel, x1, x0, out, stream=None):
+        g = sel.shape[0]
+        w = g * self.params.n1
+        _check(library().tfhe_amd_mux_batch_device(self._h, _dev_ptr(sel, w), _dev_ptr(x1, w), _dev_ptr(x0, w),
+                                                   _dev_ptr(out, w), g, self._stream_ptr(stream)))
         return out
 
     def bootstrap_device(self, c, out, stream=None):

@@ -1,13 +1,21 @@
-"""Level-scheduled evaluation of NAND netlists: every gate of a dependency level goes into one
+"""Level-scheduled evaluation of gate netlists: every gate of a dependency level goes into one
 batched call (reference: each gate is one HomNAND::nand call, src/hom_nand.hpp:74-81; the
 reference's own chained network is test/main.cpp:192-205).
 
-A netlist is a list of gates (out_wire, in_a, in_b) over integer wire ids.  Wires that no gate
-drives are inputs.  `levelize` assigns every gate the earliest level at which both operands
-exist; `evaluate` walks the levels, gathering operand rows from a [n_wires, n+1] wire array,
-calling a batched NAND, and scattering the results back.
+A netlist is a list of gates over integer wire ids:
+    (out, a, b)              NAND, the reference's only gate
+    (out, a, b, op)          op in binding.GATES ("and", "or", "xor", ...): the same bootstrap
+                             behind another linear combination of the operands
+    (out, a, None, "not")    negation, no bootstrap
+    (out, sel, x1, "mux", x0)   sel ? x1 : x0, two blind rotations and one key switch
+Wires that no gate drives are inputs.  `levelize` assigns every gate the earliest level at which
+all its operands exist; `evaluate` walks the levels, gathering operand rows from a
+[n_wires, n+1] wire array, calling the backend once per kind of gate present in the level
+(all two-input gates of a level share one call), and scattering the results back.
 """
 import numpy as np
+
+from .binding import GATES
 
 MU = 1 << 29
 
@@ -19,43 +27,58 @@ def trivial_bit(bit, n1):
     return ct
 
 
+def normalize(gate):
+    """(out, op, inputs) of a netlist entry."""
+    if len(gate) == 3:
+        return gate[0], "nand", (gate[1], gate[2])
+    op = gate[3]
+    if op == "not":
+        return gate[0], op, (gate[1],)
+    if op == "mux":
+        if len(gate) != 5:
+            raise ValueError("mux gates are (out, sel, x1, 'mux', x0)")
+        return gate[0], op, (gate[1], gate[2], gate[4])
+    if op not in GATES:
+        raise ValueError(f"unknown gate {op!r}")
+    return gate[0], op, (gate[1], gate[2])
+
+
 def levelize(gates, n_wires):
     """Returns a list of levels, each a list of gate indices.  Raises on a combinational loop
     or a wire driven twice."""
+    norm = [normalize(g) for g in gates]
     driver = {}
-    for g, (o, _, _) in enumerate(gates):
+    for g, (o, _, _) in enumerate(norm):
         if o in driver:
             raise ValueError(f"wire {o} is driven by gates {driver[o]} and {g}")
         if not 0 <= o < n_wires:
             raise ValueError(f"gate {g} drives wire {o} outside [0, {n_wires})")
         driver[o] = g
-    level_of_wire = {}
     level_of_gate = [None] * len(gates)
-
-    def wire_level(w, stack):
-        if w not in driver:
-            return 0
-        if w in level_of_wire:
-            return level_of_wire[w]
-        g = driver[w]
-        if g in stack:
-            raise ValueError("combinational loop through wire %d" % w)
-        stack.add(g)
-        _, a, b = gates[g]
-        lv = 1 + max(wire_level(a, stack), wire_level(b, stack))
-        stack.discard(g)
-        level_of_wire[w] = lv
-        level_of_gate[g] = lv
-        return lv
-
-    import sys
-    old = sys.getrecursionlimit()
-    sys.setrecursionlimit(max(old, 4 * len(gates) + 100))
-    try:
-        for g, (o, _, _) in enumerate(gates):
-            wire_level(o, set())
-    finally:
-        sys.setrecursionlimit(old)
+    # iterative depth-first search: state 0 = enter, 1 = operands done
+    for root in range(len(gates)):
+        if level_of_gate[root] is not None:
+            continue
+        stack = [(root, 0)]
+        on_path = set()
+        while stack:
+            g, state = stack.pop()
+            if state == 0:
+                if level_of_gate[g] is not None:
+                    continue
+                if g in on_path:
+                    raise ValueError("combinational loop through wire %d" % norm[g][0])
+                on_path.add(g)
+                stack.append((g, 1))
+                for w in norm[g][2]:
+                    d = driver.get(w)
+                    if d is not None and level_of_gate[d] is None:
+                        if d in on_path:
+                            raise ValueError("combinational loop through wire %d" % w)
+                        stack.append((d, 0))
+            else:
+                on_path.discard(g)
+                level_of_gate[g] = 1 + max((level_of_gate[driver[w]] if w in driver else 0) for w in norm[g][2])
     depth = max(level_of_gate, default=0)
     levels = [[] for _ in range(depth)]
     for g, lv in enumerate(level_of_gate):
@@ -85,26 +108,139 @@ def ripple_carry_adder(bits):
     return gates, nxt, a, b, zero, sums, cin
 
 
-def evaluate(gates, wires, nand_batch, levels=None):
-    """Evaluates the netlist in place on `wires` ([n_wires, n+1] numpy uint32, or a torch tensor
-    when nand_batch works on tensors).  nand_batch(a_rows, b_rows) -> out_rows.  With tensors,
-    nand_batch must enqueue on torch's current stream (Context.nand_device(..., stream=
-    torch.cuda.current_stream())) so that it is ordered with the gathers and scatters here.
-    Returns the number of levels executed."""
+def mux_adder(bits):
+    """Ripple-carry adder with one gate per bit on the carry chain: x = a xor b,
+    cout = x ? cin : a, sum = x xor cin.  3 gates (4 blind rotations) per bit and bits + 2 levels,
+    against 9 gates and 2 bits + 4 levels for the NAND-only form.  Same return layout as
+    ripple_carry_adder."""
+    a = list(range(bits))
+    b = list(range(bits, 2 * bits))
+    zero = 2 * bits
+    nxt = 2 * bits + 1
+    gates, sums = [], []
+    cin = zero
+    for i in range(bits):
+        x, s, cout = range(nxt, nxt + 3)
+        nxt += 3
+        gates += [(x, a[i], b[i], "xor"), (cout, x, cin, "mux", a[i]), (s, x, cin, "xor")]
+        sums.append(s)
+        cin = cout
+    return gates, nxt, a, b, zero, sums, cin
+
+
+class HostBackend:
+    """numpy rows through the host-pointer entry points: one call per gate type in a level."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def gates(self, ops, a, b):
+        out = np.empty_like(a)
+        ops = np.asarray(ops)
+        for op in np.unique(ops):
+            sel = np.nonzero(ops == op)[0]
+            out[sel] = self.ctx.gate(int(op), np.ascontiguousarray(a[sel]), np.ascontiguousarray(b[sel]))
+        return out
+
+    def not_(self, a):
+        return self.ctx.not_(a)
+
+    def mux(self, sel, x1, x0):
+        return self.ctx.mux(sel, x1, x0)
+
+
+class DeviceBackend:
+    """torch GPU rows through the device-pointer entry points, enqueued on torch's current stream
+    so that they are ordered with the gathers and scatters of `evaluate`; all two-input gates of
+    a level go into one call with per-gate codes."""
+
+    def __init__(self, ctx):
+        import torch
+
+        self.ctx = ctx
+        self.torch = torch
+
+    def _stream(self):
+        return self.torch.cuda.current_stream()
+
+    def gates(self, ops, a, b):
+        ops_t = self.torch.tensor(np.asarray(ops, dtype=np.uint8), device=a.device)
+        return self.ctx.gate_device(ops_t, a, b, self.torch.empty_like(a), stream=self._stream())
+
+    def not_(self, a):
+        return self.ctx.not_device(a, self.torch.empty_like(a), stream=self._stream())
+
+    def mux(self, sel, x1, x0):
+        return self.ctx.mux_device(sel, x1, x0, self.torch.empty_like(sel), stream=self._stream())
+
+    def level(self, ops, a, b, x0, n_mux):
+        """Two-input gates (codes `ops`) followed by n_mux MUX gates, one launch."""
+        ops_t = self.torch.tensor(np.asarray(ops, dtype=np.uint8), device=a.device) if len(ops) else None
+        return self.ctx.level_device(ops_t, a, b, x0, self.torch.empty_like(a), n_mux, stream=self._stream())
+
+
+class _NandOnly:
+    """Adapter for a plain nand_batch(a, b) callable."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def gates(self, ops, a, b):
+        if any(int(o) != 0 for o in ops):
+            raise ValueError("this backend evaluates NAND gates only")
+        return self.fn(a, b)
+
+
+def evaluate(gates, wires, backend, levels=None):
+    """Evaluates the netlist in place on `wires` ([n_wires, n+1] numpy uint32, or a torch GPU
+    tensor with a DeviceBackend).  `backend`: a HostBackend / DeviceBackend (or any object with
+    gates(ops, a, b), not_(a), mux(sel, x1, x0)), or a callable nand_batch(a_rows, b_rows) ->
+    out_rows for NAND-only netlists.  Returns the number of levels executed."""
+    if callable(backend) and not hasattr(backend, "gates"):
+        backend = _NandOnly(backend)
     if levels is None:
         levels = levelize(gates, wires.shape[0])
+    norm = [normalize(g) for g in gates]
     is_torch = not isinstance(wires, np.ndarray)
-    for lv in levels:
-        o = [gates[g][0] for g in lv]
-        ia = [gates[g][1] for g in lv]
-        ib = [gates[g][2] for g in lv]
-        if is_torch:
-            import torch
+    if is_torch:
+        import torch
 
-            dev = wires.device
-            ia_t, ib_t, o_t = (torch.tensor(v, dtype=torch.long, device=dev) for v in (ia, ib, o))
-            out = nand_batch(wires.index_select(0, ia_t).contiguous(), wires.index_select(0, ib_t).contiguous())
-            wires.index_copy_(0, o_t, out)
-        else:
-            wires[o] = nand_batch(np.ascontiguousarray(wires[ia]), np.ascontiguousarray(wires[ib]))
+        def rows(idx):
+            return wires.index_select(0, torch.tensor(idx, dtype=torch.long, device=wires.device)).contiguous()
+
+        def store(idx, val):
+            wires.index_copy_(0, torch.tensor(idx, dtype=torch.long, device=wires.device), val)
+    else:
+        def rows(idx):
+            return np.ascontiguousarray(wires[idx])
+
+        def store(idx, val):
+            wires[idx] = val
+
+    for lv in levels:
+        two = [g for g in lv if norm[g][1] in GATES]
+        nots = [g for g in lv if norm[g][1] == "not"]
+        muxes = [g for g in lv if norm[g][1] == "mux"]
+        # all operands are read before any result of the level is stored
+        results = []
+        if two and muxes and hasattr(backend, "level"):
+            # both kinds in one call: the level then costs one blind-rotation latency
+            order = two + muxes
+            out = backend.level([GATES[norm[g][1]] for g in two], rows([norm[g][2][0] for g in order]),
+                                rows([norm[g][2][1] for g in order]), rows([norm[g][2][2] for g in muxes]),
+                                len(muxes))
+            results.append(([norm[g][0] for g in order], out))
+            two, muxes = [], []
+        if two:
+            out = backend.gates([GATES[norm[g][1]] for g in two], rows([norm[g][2][0] for g in two]),
+                                rows([norm[g][2][1] for g in two]))
+            results.append(([norm[g][0] for g in two], out))
+        if nots:
+            results.append(([norm[g][0] for g in nots], backend.not_(rows([norm[g][2][0] for g in nots]))))
+        if muxes:
+            out = backend.mux(rows([norm[g][2][0] for g in muxes]), rows([norm[g][2][1] for g in muxes]),
+                              rows([norm[g][2][2] for g in muxes]))
+            results.append(([norm[g][0] for g in muxes], out))
+        for idx, val in results:
+            store(idx, val)
     return len(levels)

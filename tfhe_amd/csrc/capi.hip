@@ -250,8 +250,11 @@ int run_key_switch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t
     return TFHE_AMD_OK;
 }
 
-// bootstrap + key switch on device data, with optional event timing
-int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s) {
+// bootstrap + key switch on device data, with optional event timing.  The last n_mux of the
+// n_gates gates are MUXes: c holds n_gates + n_mux rows, and the lv1 result of row n_gates + j is
+// added (plus 1/8) to that of row n_gates - n_mux + j before the key switch.
+int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s,
+                  size_t n_mux = 0) {
     hipEvent_t* e = nullptr;
     if (ctx->timing) {
         if (ctx->ev_count == kTimingRing) {
@@ -261,8 +264,11 @@ int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_
         e = &ctx->ev[(size_t)((ctx->ev_head + ctx->ev_count) % kTimingRing) * 3];
         HIP_TRY(hipEventRecord(e[0], s));
     }
-    int rc = run_blind_rotate(ctx, c, nullptr, ctx->d_lv1, n_gates, 1, s);
+    int rc = run_blind_rotate(ctx, c, nullptr, ctx->d_lv1, n_gates + n_mux, 1, s);
     if (rc) return rc;
+    if (n_mux)
+        HIP_TRY(launch_mux_sum(ctx->d_lv1 + (n_gates - n_mux) * lv1_of(ctx), ctx->d_lv1 + n_gates * lv1_of(ctx), n_mux,
+                               (int)lv1_of(ctx), s));
     if (e) HIP_TRY(hipEventRecord(e[1], s));
     rc = run_key_switch(ctx, ctx->d_lv1, out, n_gates, s);
     if (rc) return rc;
@@ -271,6 +277,10 @@ int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_
         ctx->ev_count++;
     }
     return TFHE_AMD_OK;
+}
+
+int check_gate_code(int op) {
+    return (op >= 0 && op < TFHE_AMD_GATE_COUNT) ? TFHE_AMD_OK : fail(TFHE_AMD_ERR_ARGUMENT, "unknown gate code");
 }
 
 // Host-pointer wrapper: copies `n_in` input arrays to the staging buffer, runs `body` on the
@@ -475,6 +485,62 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
     return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
 }
 
+int tfhe_amd_gate_batch_device(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                               size_t n_gates, void* stream) {
+    int rc = check_batch(ctx, n_gates, a && b && out);
+    if (rc || (rc = check_gate_code(op)) || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
+    DeviceGuard guard(ctx->device);
+    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    HIP_TRY(launch_gate_combine(ctx->d_c, a, b, nullptr, op, n_gates, ctx->p.n + 1, s));
+    return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
+}
+
+int tfhe_amd_gates_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uint32_t* a, const uint32_t* b,
+                                uint32_t* out, size_t n_gates, void* stream) {
+    int rc = check_batch(ctx, n_gates, ops && a && b && out);
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
+    DeviceGuard guard(ctx->device);
+    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    HIP_TRY(launch_gate_combine(ctx->d_c, a, b, ops, 0, n_gates, ctx->p.n + 1, s));
+    return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
+}
+
+int tfhe_amd_not_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, uint32_t* out, size_t n_gates, void* stream) {
+    int rc = check_batch(ctx, n_gates, a && out);
+    if (rc || n_gates == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(launch_negate(out, a, n_gates * n1_of(ctx), pick_stream(ctx, stream)));
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_level_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uint32_t* a, const uint32_t* b,
+                                const uint32_t* x0, uint32_t* out, size_t n_gates, size_t n_mux, void* stream) {
+    if (n_mux > n_gates) return fail(TFHE_AMD_ERR_ARGUMENT, "more MUX gates than gates");
+    const size_t n_two = n_gates - n_mux;
+    int rc = check_batch(ctx, n_gates + n_mux, a && b && out && (n_two == 0 || ops) && (n_mux == 0 || x0));
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
+    DeviceGuard guard(ctx->device);
+    if ((rc = ensure_workspace(ctx, n_gates + n_mux))) return rc;
+    hipStream_t s = pick_stream(ctx, stream);
+    const size_t n1 = n1_of(ctx);
+    HIP_TRY(launch_gate_combine(ctx->d_c, a, b, ops, 0, n_two, (int)n1, s));
+    HIP_TRY(launch_gate_combine(ctx->d_c + n_two * n1, a + n_two * n1, b + n_two * n1, nullptr, TFHE_AMD_GATE_AND,
+                                n_mux, (int)n1, s));
+    HIP_TRY(launch_gate_combine(ctx->d_c + n_gates * n1, a + n_two * n1, x0, nullptr, TFHE_AMD_GATE_ANDNY, n_mux,
+                                (int)n1, s));
+    return run_bootstrap(ctx, ctx->d_c, out, n_gates, s, n_mux);
+}
+
+int tfhe_amd_mux_batch_device(tfhe_amd_ctx* ctx, const uint32_t* sel, const uint32_t* x1, const uint32_t* x0,
+                              uint32_t* out, size_t n_gates, void* stream) {
+    return tfhe_amd_level_batch_device(ctx, nullptr, sel, x1, x0, out, n_gates, n_gates, stream);
+}
+
 int tfhe_amd_gate_bootstrapping_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* lv1, size_t n_gates,
                                              void* stream) {
     int rc = check_batch(ctx, n_gates, c && lv1);
@@ -513,6 +579,44 @@ int tfhe_amd_nand_batch(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b,
     const size_t iw[2] = {w, w};
     return with_staging(ctx, in, iw, 2, out, w, [&](const uint32_t* const* d, uint32_t* o) {
         return tfhe_amd_nand_batch_device(ctx, d[0], d[1], o, n_gates, nullptr);
+    });
+}
+
+int tfhe_amd_gate_batch(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                        size_t n_gates) {
+    int rc = check_batch(ctx, n_gates, a && b && out);
+    if (rc || (rc = check_gate_code(op)) || n_gates == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    const size_t w = n_gates * n1_of(ctx);
+    const uint32_t* in[2] = {a, b};
+    const size_t iw[2] = {w, w};
+    return with_staging(ctx, in, iw, 2, out, w, [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_gate_batch_device(ctx, op, d[0], d[1], o, n_gates, nullptr);
+    });
+}
+
+int tfhe_amd_not_batch(tfhe_amd_ctx* ctx, const uint32_t* a, uint32_t* out, size_t n_gates) {
+    int rc = check_batch(ctx, n_gates, a && out);
+    if (rc || n_gates == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    const size_t w = n_gates * n1_of(ctx);
+    const uint32_t* in[1] = {a};
+    const size_t iw[1] = {w};
+    return with_staging(ctx, in, iw, 1, out, w, [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_not_batch_device(ctx, d[0], o, n_gates, nullptr);
+    });
+}
+
+int tfhe_amd_mux_batch(tfhe_amd_ctx* ctx, const uint32_t* sel, const uint32_t* x1, const uint32_t* x0, uint32_t* out,
+                       size_t n_gates) {
+    int rc = check_batch(ctx, 2 * n_gates, sel && x1 && x0 && out);
+    if (rc || n_gates == 0) return rc;
+    DeviceGuard guard(ctx->device);
+    const size_t w = n_gates * n1_of(ctx);
+    const uint32_t* in[3] = {sel, x1, x0};
+    const size_t iw[3] = {w, w, w};
+    return with_staging(ctx, in, iw, 3, out, w, [&](const uint32_t* const* d, uint32_t* o) {
+        return tfhe_amd_mux_batch_device(ctx, d[0], d[1], d[2], o, n_gates, nullptr);
     });
 }
 
@@ -610,6 +714,6 @@ int tfhe_amd_ctx_timing(tfhe_amd_ctx* ctx, double* blind_rotate_ms, double* key_
 }
 
 const char* tfhe_amd_last_error(void) { return g_last_error.c_str(); }
-const char* tfhe_amd_version(void) { return "0.2.0"; }
+const char* tfhe_amd_version(void) { return "0.3.0"; }
 
 }  // extern "C"

@@ -24,6 +24,56 @@ __global__ void __launch_bounds__(256) nand_combine_kernel(uint32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Linear step of the other two-input gates: c = (offset, 0, ..) + sa * a + sb * b, the
+// generalisation of the NAND line (reference src/hom_nand.hpp:76-78; the reference has no other
+// gate).  true = +1/8, false = -1/8 (reference src/types.hpp:25,34).  Codes: tfhe_amd.h.
+// `ops` (one code per gate, device memory) overrides `op` when not null; codes are validated on
+// the host for `op` and clamped here for `ops` (an unknown code evaluates as NAND).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gate_coefficients(int op, uint32_t& offset, uint32_t& sa, uint32_t& sb) {
+    const uint32_t mu = 1u << 29, q = 1u << 30, m1 = 0xffffffffu, m2 = 0xfffffffeu;
+    switch (op) {
+    default: offset = mu;      sa = m1; sb = m1; break;  // NAND
+    case 1:  offset = 0u - mu; sa = 1;  sb = 1;  break;  // AND
+    case 2:  offset = mu;      sa = 1;  sb = 1;  break;  // OR
+    case 3:  offset = 0u - mu; sa = m1; sb = m1; break;  // NOR
+    case 4:  offset = q;       sa = 2;  sb = 2;  break;  // XOR
+    case 5:  offset = 0u - q;  sa = m2; sb = m2; break;  // XNOR
+    case 6:  offset = 0u - mu; sa = m1; sb = 1;  break;  // ANDNY
+    case 7:  offset = 0u - mu; sa = 1;  sb = m1; break;  // ANDYN
+    case 8:  offset = mu;      sa = m1; sb = 1;  break;  // ORNY
+    case 9:  offset = mu;      sa = 1;  sb = m1; break;  // ORYN
+    }
+}
+
+__global__ void __launch_bounds__(256) gate_combine_kernel(uint32_t* __restrict__ c, const uint32_t* __restrict__ a,
+                                                           const uint32_t* __restrict__ b,
+                                                           const uint8_t* __restrict__ ops, int op, size_t total,
+                                                           int n1) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t g = i / (size_t)n1;
+    uint32_t offset, sa, sb;
+    gate_coefficients(ops ? (int)ops[g] : op, offset, sa, sb);
+    c[i] = sa * a[i] + sb * b[i] + (i - g * (size_t)n1 == 0 ? offset : 0u);
+}
+
+// out = -a: homomorphic NOT, no bootstrap
+__global__ void __launch_bounds__(256) negate_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ a,
+                                                     size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = 0u - a[i];
+}
+
+// MUX, lv1 stage: dst[j] = dst[j] + src[j] + (1/8, 0, ..) over `total` words in rows of n1 words
+__global__ void __launch_bounds__(256) mux_sum_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src,
+                                                      size_t total, int n1) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    dst[i] = dst[i] + src[i] + ((i % (size_t)n1) == 0 ? (1u << 29) : 0u);
+}
+
+// ------------------------------------------------------------------------------------------
 // Bootstrapping key -> NTT domain.  One wave per polynomial.  The stored value is
 // NTT(centred bk) / N, centred, as a double.  Storage order inside a polynomial: pair index
 // kk in 0..3, lane, two values (registers 2kk, 2kk+1 of layout C), so that one wave reads
@@ -566,6 +616,27 @@ hipError_t launch_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b
     if (total == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((total + 255) / 256);
     nand_combine_kernel<<<blocks, 256, 0, stream>>>(c, a, b, total, n1);
+    return hipGetLastError();
+}
+
+hipError_t launch_gate_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, const uint8_t* ops, int op,
+                               size_t n_gates, int n1, hipStream_t stream) {
+    const size_t total = n_gates * (size_t)n1;
+    if (total == 0) return hipSuccess;
+    gate_combine_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(c, a, b, ops, op, total, n1);
+    return hipGetLastError();
+}
+
+hipError_t launch_negate(uint32_t* out, const uint32_t* a, size_t words, hipStream_t stream) {
+    if (words == 0) return hipSuccess;
+    negate_kernel<<<(unsigned)((words + 255) / 256), 256, 0, stream>>>(out, a, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_mux_sum(uint32_t* dst, const uint32_t* src, size_t n_rows, int lv1_words, hipStream_t stream) {
+    const size_t total = n_rows * (size_t)lv1_words;
+    if (total == 0) return hipSuccess;
+    mux_sum_kernel<<<(unsigned)((total + 255) / 256), 256, 0, stream>>>(dst, src, total, lv1_words);
     return hipGetLastError();
 }
 

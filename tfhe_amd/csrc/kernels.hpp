@@ -11,6 +11,12 @@ namespace tfhe_amd {
 
 hipError_t launch_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, size_t n_gates, int n1,
                                hipStream_t stream);
+// c = (offset, 0, ..) + sa * a + sb * b per gate; `ops` (device, one code per gate) overrides `op`
+hipError_t launch_gate_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, const uint8_t* ops, int op,
+                               size_t n_gates, int n1, hipStream_t stream);
+hipError_t launch_negate(uint32_t* out, const uint32_t* a, size_t words, hipStream_t stream);
+// dst[j] += src[j] + (1/8, 0, ..) over n_rows rows of lv1_words words
+hipError_t launch_mux_sum(uint32_t* dst, const uint32_t* src, size_t n_rows, int lv1_words, hipStream_t stream);
 hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint32_t* bk, d2* bk_ntt, int n_polys,
                                    hipStream_t stream);
 // tv: test vector [K+1][N] shared by all gates or nullptr (gate bootstrapping); extract != 0
