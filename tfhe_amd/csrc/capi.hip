@@ -12,6 +12,7 @@
 #include "../../include/tfhe_amd.h"
 #include "field.hpp"
 #include "kernels.hpp"
+#include "ntt512_half.hpp"
 #include "ntt_wg.hpp"
 
 using namespace tfhe_amd;
@@ -118,7 +119,7 @@ void build_uniform(NttUniform& u, const TwiddleSet& t) {
 
 // LDS twiddle block for N = 512 (section layout in ntt512.hpp)
 std::vector<double> build_tw_block_512(const TwiddleSet& t) {
-    std::vector<double> blk((size_t)kTwPairs * 2);
+    std::vector<double> blk((size_t)(kTwPairs + kHalfPairs) * 2);
     auto put = [&](int pair, uint64_t v) {
         const TwPair tp = tw_pair(v);
         blk[(size_t)pair * 2] = tp.w;
@@ -136,6 +137,20 @@ std::vector<double> build_tw_block_512(const TwiddleSet& t) {
     fill(kTwFwdC, 64, 64, t.fwd);
     fill(kTwInvB, 8, 8, t.inv);
     fill(kTwInvC, 64, 64, t.inv);
+    // table of the two-wave transform (ntt512_half.hpp), appended: forward rows, then inverse rows;
+    // group g starts at stage 2g - 1 with m = 2^(2g-1) rows [tab[m + U], tab[2m + 2U], tab[2m + 2U + 1]]
+    for (int dir = 0; dir < 2; dir++) {
+        const std::vector<uint64_t>& tab = dir ? t.inv : t.fwd;
+        for (int g = 1; g <= 4; g++) {
+            const int m = 1 << (2 * g - 1);
+            for (int U = 0; U < m; U++) {
+                const int pair = kTwPairs + 3 * (dir * kHalfRows + half_row_offset(g) + U);
+                put(pair, tab[m + U]);
+                put(pair + 1, tab[2 * m + 2 * U]);
+                put(pair + 2, tab[2 * m + 2 * U + 1]);
+            }
+        }
+    }
     return blk;
 }
 

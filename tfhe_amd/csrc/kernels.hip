@@ -9,6 +9,7 @@
 //                                                                    reference src/tlwe_key_switching.hpp:47-65
 #include "kernels.hpp"
 #include "ntt512.hpp"
+#include "ntt512_half.hpp"
 
 namespace tfhe_amd {
 
@@ -123,14 +124,9 @@ __global__ void __launch_bounds__(256) bk_transform_512_kernel(const NttUniform 
 #ifndef TFHE_AMD_PIN_THROUGHPUT
 #define TFHE_AMD_PIN_THROUGHPUT 1
 #endif
-#ifndef TFHE_AMD_PIN_LATENCY
-#define TFHE_AMD_PIN_LATENCY 0
-#endif
-// Phase-ordered butterflies (ntt512.hpp) per kernel form.  Measured on 8,192 gates: 47.6 -> 46.3 ms
-// for the throughput form (two waves per SIMD still leave dependent-issue gaps); no change for
-// the latency form, whose waves are bound by the single-wave issue rate either way.
+// Phase-ordered butterflies (ntt512.hpp) in the throughput form.  Measured on 8,192 gates:
+// 47.6 -> 46.3 ms (two waves per SIMD still leave dependent-issue gaps).
 constexpr bool kPinThroughput = TFHE_AMD_PIN_THROUGHPUT != 0;
-constexpr bool kPinLatency = TFHE_AMD_PIN_LATENCY != 0;
 
 template <int K, int L>
 __global__ void __launch_bounds__(256, 2)
@@ -293,30 +289,40 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
 }
 
 // ------------------------------------------------------------------------------------------
-// Blind rotation for small batches (latency form).  One WORKGROUP owns one gate and its
-// (K+1)*L waves split each step: wave r decomposes, transforms and multiplies digit polynomial
-// r (phase 1, partial products to LDS); after a barrier waves 0..K sum the partial products of
-// their column, inverse-transform and update the accumulator (phase 2).  The dependent chain per
-// step is one forward transform, one multiply, one inverse transform instead of six, eighteen
-// and three.  Same arithmetic, same results as blind_rotate_512_kernel.
+// Blind rotation for small batches (latency form).  One WORKGROUP owns one gate; every
+// length-512 transform is split over two waves (ntt512_half.hpp), so a step is spread over
+// 2 (K+1) L = 12 waves, three per SIMD:
+//   phase 1: wave (r, h) decomposes digit polynomial r, transforms half h of it and multiplies
+//            with half h of key row r (partial products to LDS);
+//   phase 2: wave (col, h) sums the partial products of half h of column col and
+//            inverse-transforms them up to the last stage;
+//   phase 3: the last stage pairs the two halves through LDS; wave (col, h) finishes positions
+//            256 h .. 256 h + 255 and updates the accumulator.
+// Against one wave per gate (blind_rotate_512_kernel) the dependent chain of a step is one half
+// forward transform, one multiply and one half inverse transform instead of six, eighteen and
+// three whole ones, and all four SIMDs carry the same load in phase 1 (a variant with one wave per
+// transform, six waves, measured 2.74 ms per gate against 2.46 ms for this one).  Same arithmetic,
+// same results.  `tw_half`: the table of ntt512_half.hpp.
 // ------------------------------------------------------------------------------------------
 template <int K, int L>
-__global__ void __launch_bounds__(64 * (K + 1) * L, 1)
-blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw, const d2* __restrict__ bk_ntt,
-                                const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv,
-                                uint32_t* __restrict__ out, int n_gates, int n, int extract) {
-    constexpr int K1 = K + 1, R = K1 * L, BG = 8, THREADS = 64 * R;
-    __shared__ d2 s_tw[kTwPairs];
-    __shared__ double s_tr[R][kTrPad];
+__global__ void __launch_bounds__(128 * (K + 1) * L, 1)
+blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_half, const d2* __restrict__ bk_ntt,
+                              const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv,
+                              uint32_t* __restrict__ out, int n_gates, int n, int extract) {
+    constexpr int K1 = K + 1, R = K1 * L, BG = 8, WAVES = 2 * R, THREADS = 64 * WAVES;
+    __shared__ d2 s_tw[kHalfPairs];
+    __shared__ double s_tr[WAVES][kHalfTrWords];
     __shared__ uint32_t s_acc[K1][kN];
-    __shared__ double s_part[R][K1][kN];  // [digit polynomial][column][register k * 64 + lane]
+    __shared__ double s_part[R][K1][kN];  // [digit polynomial][column][256 h + 64 k + lane]
+    __shared__ double s_x[K1][kN];        // inverse halves before the last stage, [column][256 h + 64 k + lane]
 
-    for (int i = threadIdx.x; i < kTwPairs; i += THREADS) s_tw[i] = tw[i];
-    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < kHalfPairs; i += THREADS) s_tw[i] = tw_half[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = w >> 1, h = w & 1;
     const int gate = blockIdx.x;
     const uint32_t* cg = c + (size_t)gate * (n + 1);
     const double p = u.p, pinv = u.pinv;
-    double* tr = s_tr[r];
+    double* tr = s_tr[w];
 
     {
         const int bbar = (int)(cg[0] >> 22);
@@ -337,15 +343,16 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw, c
     }
     const int q = r / L, level = r % L;
 
-    // Key row r of step i + 1 is requested at the top of step i: with one gate per workgroup the
-    // rows come from the Infinity Cache or HBM, and a full step hides that latency.
-    d2 y[K1][4], ynext[K1][4];
+    // This wave's share of a key polynomial: spectrum positions 256 h + 4 lane + k, i.e. pairs
+    // kk = 2 (lane & 1) + {0, 1} of lane 32 h + (lane >> 1) in the stored [4][64][2] order.
+    const int key_off = (2 * (lane & 1)) * 64 + 32 * h + (lane >> 1);
+    d2 y[K1][2], ynext[K1][2];
     {
-        const d2* bk_poly = bk_ntt + (size_t)r * K1 * (kN / 2);
+        const d2* bk_poly = bk_ntt + (size_t)r * K1 * (kN / 2) + key_off;
 #pragma unroll
         for (int col = 0; col < K1; col++)
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) ynext[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+            for (int t = 0; t < 2; t++) ynext[col][t] = bk_poly[col * (kN / 2) + t * 64];
     }
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
@@ -353,19 +360,19 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw, c
         const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cvals, i & 63);
         const int abar = (int)((ci + (1u << 21)) >> 22);
 
-        // ---- phase 1: digit polynomial r -> NTT -> products with key row r ----
+        // ---- phase 1 ----
 #pragma unroll
         for (int col = 0; col < K1; col++)
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) y[col][kk] = ynext[col][kk];
+            for (int t = 0; t < 2; t++) y[col][t] = ynext[col][t];
         if (i + 1 < n) {
-            const d2* bk_poly = bk_ntt + ((size_t)(i + 1) * R + r) * K1 * (kN / 2);
+            const d2* bk_poly = bk_ntt + ((size_t)(i + 1) * R + r) * K1 * (kN / 2) + key_off;
 #pragma unroll
             for (int col = 0; col < K1; col++)
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) ynext[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+                for (int t = 0; t < 2; t++) ynext[col][t] = bk_poly[col * (kN / 2) + t * 64];
         }
-        double x[8];
+        double d[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int j = 64 * k + lane;
@@ -373,49 +380,53 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw, c
             const uint32_t neg = 0u - (uint32_t)((sidx >> 9) & 1);
             const uint32_t v = s_acc[q][sidx & (kN - 1)];
             const uint32_t t = ((((v ^ neg) - neg) - s_acc[q][j]) + offset) ^ flip;
-            x[k] = (double)(((int32_t)(t << (BG * level))) >> (32 - BG));
+            d[k] = (double)(((int32_t)(t << (BG * level))) >> (32 - BG));
         }
-        ntt512_forward<true, false, kPinLatency>(x, u, s_tw, tr, lane);
+        double x[4];
+        half_forward_small(x, d, h, u, s_tw, tr, lane);  // |x| <= 2.2 p
 #pragma unroll
-        for (int col = 0; col < K1; col++) {
-            if (kPinLatency) {
-                double yy[8], prod[8];
+        for (int col = 0; col < K1; col++)
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    yy[2 * kk] = y[col][kk].x;
-                    yy[2 * kk + 1] = y[col][kk].y;
-                }
-                mulmod_var_n<8>(prod, x, yy, p, pinv);
-#pragma unroll
-                for (int k = 0; k < 8; k++) s_part[r][col][k * 64 + lane] = prod[k];
-                continue;
+            for (int k = 0; k < 4; k++) {
+                const double yk = (k & 1) ? y[col][k >> 1].y : y[col][k >> 1].x;
+                s_part[r][col][256 * h + 64 * k + lane] = mulmod_var(x[k], yk, p, pinv);  // <= 1.13 p
             }
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                s_part[r][col][(2 * kk) * 64 + lane] = mulmod_var(x[2 * kk], y[col][kk].x, p, pinv);
-                s_part[r][col][(2 * kk + 1) * 64 + lane] = mulmod_var(x[2 * kk + 1], y[col][kk].y, p, pinv);
-            }
-        }
         __syncthreads();
 
-        // ---- phase 2: column r of the result (waves 0..K) ----
+        // ---- phase 2: half h of column r (waves with r <= K) ----
+        uint32_t acc_old[4];
         if (r < K1) {
-            double sum[8];
+            double sum[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) sum[k] = 0.0;
+            for (int k = 0; k < 4; k++) sum[k] = 0.0;
 #pragma unroll
             for (int rr = 0; rr < R; rr++) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) sum[k] += s_part[rr][r][k * 64 + lane];
-                // each product is <= 1.41 p: reduce after every third so the sum stays < 4.74 p
+                for (int k = 0; k < 4; k++) sum[k] += s_part[rr][r][256 * h + 64 * k + lane];
+                // reduce after every third product: the running sum stays below 0.5 p + 3 * 1.13 p
                 if (rr % 3 == 2 && rr != R - 1) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) sum[k] = reduce(sum[k], p, pinv);
+                    for (int k = 0; k < 4; k++) sum[k] = reduce(sum[k], p, pinv);
                 }
             }
-            ntt512_inverse<kPinLatency>(sum, u, s_tw, tr, lane);
+            half_inverse(sum, h, u, s_tw + 3 * kHalfRows, tr, lane);  // |sum| <= 2 p
 #pragma unroll
-            for (int k = 0; k < 8; k++) s_acc[r][64 * k + lane] += to_torus(sum[k], p, pinv);
+            for (int k = 0; k < 4; k++) s_x[r][256 * h + 64 * k + lane] = sum[k];
+            // the accumulator words this wave will update (nobody else writes them): fetched
+            // here so that phase 3 has one LDS round trip less
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc_old[k] = s_acc[r][256 * h + 64 * k + lane];
+        }
+        __syncthreads();
+
+        // ---- phase 3: last stage (distance 256, twiddle index 1) and accumulator update ----
+        if (r < K1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double a = s_x[r][64 * k + lane], b = s_x[r][256 + 64 * k + lane];
+                const double v = h ? mulmod_tw(a - b, u.iw[1], u.iwp[1], p) : a + b;
+                s_acc[r][256 * h + 64 * k + lane] = acc_old[k] + to_torus(v, p, pinv);
+            }
         }
         __syncthreads();
     }
@@ -657,8 +668,8 @@ hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* 
     if (!(K == 2 && L == 2)) return hipErrorInvalidValue;
     const bool latency = form == 1 || (form == 0 && n_gates <= kLatencyMaxGates);
     if (latency) {
-        blind_rotate_512_latency_kernel<2, 2><<<(unsigned)n_gates, 64 * 6, 0, stream>>>(u, tw, bk_ntt, c, tv, out,
-                                                                                      n_gates, n, extract);
+        blind_rotate_512_latency_kernel<2, 2><<<(unsigned)n_gates, 128 * 6, 0, stream>>>(u, tw + kTwPairs, bk_ntt, c, tv,
+                                                                                       out, n_gates, n, extract);
     } else {
         const unsigned blocks = (unsigned)((n_gates + 3) / 4);
         blind_rotate_512_kernel<2, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, tv, out, n_gates, n, extract);

@@ -1,0 +1,174 @@
+// The length-512 negacyclic NTT of ntt512.hpp split over TWO waves, for the latency form of the
+// blind rotation: after the first radix-2 stage (distance 256) the two halves of the vector are
+// independent length-256 transforms, so wave h in {0, 1} computes stage 0 for its own half from
+// the (cheap, 8-bit) inputs and then owns positions 256 h .. 256 h + 255: 4 coefficients per lane,
+// four groups of two radix-2 stages in registers, three transposes through a private LDS buffer.
+// Same field, same modular arithmetic, same spectrum order as ntt512.hpp: the half-h wave ends
+// with spectrum positions 256 h + 4 lane + k, which in the full transform's layout C
+// (position 8 l + k) are lane l = 32 h + (lane >> 1), registers 4 (lane & 1) + k.
+//
+// Lane/register <-> position maps inside a half (j' = 8-bit position, l = lane, k = register):
+//     layout 1: j' = 64 k + l                          (distance 128, 64)
+//     layout 2: j' = 64 (l >> 4) + 16 k + (l & 15)     (distance 32, 16)
+//     layout 3: j' = 16 (l >> 2) + 4 k + (l & 3)       (distance 8, 4)
+//     layout 4: j' = 4 l + k                           (distance 2, 1)
+// Twiddles: group g = 1..4 starts at stage s = 2g - 1 with m = 2^s blocks; a lane reads row
+// U = (block index of its positions at stage s) = m h / 2 + (lane bits above the group's register
+// bits) of a table of rows [tw[m + U], tw[2m + 2U], tw[2m + 2U + 1]].
+#pragma once
+
+#include "ntt512.hpp"
+
+namespace tfhe_amd {
+
+struct Tw3 {
+    double w[3], wp[3];  // [0] first stage of the group (both butterflies), [1..2] second stage
+};
+
+constexpr int kHalfRows = 2 + 8 + 32 + 128;    // groups 1..4, both halves
+constexpr int kHalfPairs = 2 * kHalfRows * 3;  // forward rows, then inverse rows
+constexpr int kHalfTrWords = 320;              // private transpose buffer, doubles per wave
+
+__host__ __device__ constexpr int half_row_offset(int g) { return g == 1 ? 0 : (g == 2 ? 2 : (g == 3 ? 10 : 42)); }
+
+__device__ __forceinline__ void load_tw3(Tw3& t, const d2* row) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const d2 v = row[i];
+        t.w[i] = v.x;
+        t.wp[i] = v.y;
+    }
+}
+
+// table row of a lane for group g
+template <int G>
+__device__ __forceinline__ int half_row(int h, int lane) {
+    if (G == 1) return h;
+    if (G == 2) return 4 * h + (lane >> 4);
+    if (G == 3) return 16 * h + (lane >> 2);
+    return 64 * h + lane;
+}
+
+template <int LAYOUT>
+__device__ __forceinline__ int half_pos(int l, int k) {
+    if (LAYOUT == 1) return 64 * k + l;
+    if (LAYOUT == 2) return 64 * (l >> 4) + 16 * k + (l & 15);
+    if (LAYOUT == 3) return 16 * (l >> 2) + 4 * k + (l & 3);
+    return 4 * l + k;
+}
+
+// Padding of the transpose between layouts T and T + 1, chosen so that the 32 lanes of a pass
+// of an 8-byte LDS access fall on 32 different bank pairs in both layouts.
+template <int T>
+__device__ __forceinline__ int half_pad(int j) {
+    if (T == 1) return j + 16 * (j >> 6);
+    if (T == 2) return j + 4 * (j >> 4);
+    return j + (j >> 2);
+}
+
+template <int FROM, int TO>
+__device__ __forceinline__ void half_transpose(double (&x)[4], double* tr, int lane) {
+    constexpr int T = FROM < TO ? FROM : TO;
+#pragma unroll
+    for (int k = 0; k < 4; k++) tr[half_pad<T>(half_pos<FROM>(lane, k))] = x[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = tr[half_pad<T>(half_pos<TO>(lane, k))];
+    wave_lds_fence();
+}
+
+// two Cooley-Tukey stages on 4 registers: pairs (0,2), (1,3), then (0,1), (2,3)
+template <bool REDUCE_A>
+__device__ __forceinline__ void ct4(double (&x)[4], const Tw3& t, double p, double pinv) {
+    if (REDUCE_A) {
+        x[0] = reduce(x[0], p, pinv);
+        x[1] = reduce(x[1], p, pinv);
+    }
+    bf_ct(x[0], x[2], t.w[0], t.wp[0], p);
+    bf_ct(x[1], x[3], t.w[0], t.wp[0], p);
+    bf_ct(x[0], x[1], t.w[1], t.wp[1], p);
+    bf_ct(x[2], x[3], t.w[2], t.wp[2], p);
+}
+
+__device__ __forceinline__ void gs4_near(double (&x)[4], const Tw3& t, double p) {  // pairs (0,1), (2,3)
+    bf_gs(x[0], x[1], t.w[1], t.wp[1], p);
+    bf_gs(x[2], x[3], t.w[2], t.wp[2], p);
+}
+__device__ __forceinline__ void gs4_far(double (&x)[4], const Tw3& t, double p) {  // pairs (0,2), (1,3)
+    bf_gs(x[0], x[2], t.w[0], t.wp[0], p);
+    bf_gs(x[1], x[3], t.w[0], t.wp[0], p);
+}
+
+// Forward transform of 8-bit digits, half h.  d[k] = digit at position 64 k + lane of the full
+// vector (k = 0..7, the full transform's layout A).  Out: layout 4 of half h, |x| <= 2.2 p.
+//
+// Stages 0 and 1 need no reduction: with I = zeta^2 and the stage-1 twiddle W = zeta (h = 0) or
+// zeta^3 (h = 1), u_k = d_k +- I d_(k+4) and W u_(k+2) = c1 d_(k+2) + c2 d_(k+6) with
+// (c1, c2) = (zeta, zeta^3) or (zeta^3, zeta) (zeta^4 = -1), all below 2^46.
+// Growth afterwards in units of p (a butterfly maps bound B to B + 0.5 + 0.75 B / 5.26):
+// 0.55, 1.13, 1.79, 2.55, 3.41 after stages 2..6; stage 7 reduces its additive inputs: 1.49, 2.2.
+__device__ __forceinline__ void half_forward_small(double (&x)[4], const double (&d)[8], int h, const NttUniform& u,
+                                                   const d2* s_tw, double* tr, int lane) {
+    const double p = u.p, pinv = u.pinv;
+    const double z3 = u.z * u.zI;
+    const double cA = h ? -u.zI : u.zI, c1 = h ? z3 : u.z, c2 = h ? u.z : z3;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double a = __builtin_fma(d[k + 4], cA, d[k]);
+        const double t = __builtin_fma(d[k + 2], c1, c2 * d[k + 6]);
+        x[k] = a + t;
+        x[k + 2] = a - t;
+    }
+    Tw3 t;
+    load_tw3(t, s_tw + 3 * (half_row_offset(1) + half_row<1>(h, lane)));
+    bf_ct(x[0], x[1], t.w[1], t.wp[1], p);
+    bf_ct(x[2], x[3], t.w[2], t.wp[2], p);
+
+    half_transpose<1, 2>(x, tr, lane);
+    load_tw3(t, s_tw + 3 * (half_row_offset(2) + half_row<2>(h, lane)));
+    ct4<false>(x, t, p, pinv);
+
+    half_transpose<2, 3>(x, tr, lane);
+    load_tw3(t, s_tw + 3 * (half_row_offset(3) + half_row<3>(h, lane)));
+    ct4<false>(x, t, p, pinv);
+
+    half_transpose<3, 4>(x, tr, lane);
+    load_tw3(t, s_tw + 3 * (half_row_offset(4) + half_row<4>(h, lane)));
+    ct4<true>(x, t, p, pinv);
+}
+
+// Inverse of half h up to, not including, the last stage (distance 256, which pairs the two
+// halves).  In: layout 4, |x| < 2^53.  Out: layout 1, |x| <= 2 p.  A reduction every three
+// stages keeps the sum outputs below 4 p.
+__device__ __forceinline__ void half_inverse(double (&x)[4], int h, const NttUniform& u, const d2* s_tw_inv,
+                                             double* tr, int lane) {
+    const double p = u.p, pinv = u.pinv;
+    Tw3 t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = reduce(x[k], p, pinv);
+    load_tw3(t, s_tw_inv + 3 * (half_row_offset(4) + half_row<4>(h, lane)));
+    gs4_near(x, t, p);
+    gs4_far(x, t, p);
+
+    half_transpose<4, 3>(x, tr, lane);
+    load_tw3(t, s_tw_inv + 3 * (half_row_offset(3) + half_row<3>(h, lane)));
+    gs4_near(x, t, p);
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = reduce(x[k], p, pinv);
+    gs4_far(x, t, p);
+
+    half_transpose<3, 2>(x, tr, lane);
+    load_tw3(t, s_tw_inv + 3 * (half_row_offset(2) + half_row<2>(h, lane)));
+    gs4_near(x, t, p);
+    gs4_far(x, t, p);
+
+    half_transpose<2, 1>(x, tr, lane);
+#pragma unroll
+    for (int k = 0; k < 4; k++) x[k] = reduce(x[k], p, pinv);
+    load_tw3(t, s_tw_inv + 3 * (half_row_offset(1) + half_row<1>(h, lane)));
+    gs4_near(x, t, p);  // distance 64; the distance-128 stage follows
+    bf_gs(x[0], x[2], t.w[0], t.wp[0], p);
+    bf_gs(x[1], x[3], t.w[0], t.wp[0], p);
+}
+
+}  // namespace tfhe_amd
