@@ -29,7 +29,8 @@ def test_dropin_gpu_group():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["PolynomialXExp", "TLWE", "TRLWE", "CMUX", "KeySwitching", "HomNAND"])
+@pytest.mark.parametrize("name", ["PolynomialXExp", "TLWE", "TRLWE", "ExternalProduct", "CMUX", "Bootstrapping",
+                                  "KeySwitching", "HomNAND"])
 def test_reference_driver_on_dropin_headers(name):
     """reference test/main.cpp:13-224, unmodified, against src/*.hpp + libtfhe_amd.
     test_PolynomialXExp FAILS on the reference itself (its FFT product is not exact) and passes here."""
