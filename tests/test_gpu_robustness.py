@@ -1,0 +1,117 @@
+"""Behaviour of the C ABI around the hot path on a real GPU: error returns, several contexts,
+caller streams, workspace growth.  Results are checked against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def keysets():
+    p = O.params_default()
+    return p, O.keyset(p, seed=41), O.keyset(p, seed=42)
+
+
+def _enc(p, s0, n, seed):
+    rs = np.random.RandomState(seed)
+    r = O.rng(seed)
+    ba, bb = rs.randint(0, 2, n), rs.randint(0, 2, n)
+    return ba, bb, O.encrypt_bits(ba, s0, p, r), O.encrypt_bits(bb, s0, p, r)
+
+
+def test_context_without_a_key_refuses_the_stage_that_needs_it(keysets):
+    import tfhe_amd
+
+    p, (s0, sr, bk, ks), _ = keysets
+    _, _, a, b = _enc(p, s0, 2, 1)
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, None) as ctx:
+        with pytest.raises(tfhe_amd.TfheAmdError, match="key-switching key"):
+            ctx.nand(a, b)
+        c = np.stack([O.nand_combine(x, y, p) for x, y in zip(a, b)])
+        lv1 = ctx.gate_bootstrapping_tlwe_to_tlwe(c)       # needs the bootstrapping key only
+        assert lv1.shape == (2, p.lv1 + 1)
+    with tfhe_amd.Context(tfhe_amd.params_default(), None, ks) as ctx:
+        with pytest.raises(tfhe_amd.TfheAmdError, match="bootstrapping key"):
+            ctx.nand(a, b)
+        assert np.array_equal(ctx.identity_key_switch(lv1), np.stack([O.identity_key_switch(l, ks, p) for l in lv1]))
+
+
+def test_unsupported_and_invalid_parameter_sets():
+    import tfhe_amd
+
+    with pytest.raises(tfhe_amd.TfheAmdError):      # ring beyond every kernel
+        tfhe_amd.Context(tfhe_amd.Params(8, 4096, 1, 8, 2, 5, 2), None, None)
+    with pytest.raises(tfhe_amd.TfheAmdError):      # L * bg_bit > 31
+        tfhe_amd.Context(tfhe_amd.Params(8, 16, 1, 8, 4, 5, 2), None, None)
+    with pytest.raises(tfhe_amd.TfheAmdError):      # no such device
+        tfhe_amd.Context(tfhe_amd.params_default(), None, None, device=99)
+    with pytest.raises(ValueError):                 # key size does not match the parameters
+        tfhe_amd.Context(tfhe_amd.params_default(), np.zeros(10, dtype=np.uint32), None)
+
+
+def test_two_contexts_with_different_keys_interleaved(keysets):
+    import tfhe_amd
+
+    p, k1, k2 = keysets
+    ctxs = [tfhe_amd.Context(tfhe_amd.params_default(), k[2], k[3]) for k in (k1, k2)]
+    octxs = [O.Context(p, k[2], k[3]) for k in (k1, k2)]
+    try:
+        for rnd in range(2):
+            for i, k in enumerate((k1, k2)):
+                ba, bb, a, b = _enc(p, k[0], 3, 10 * rnd + i)
+                got = ctxs[i].nand(a, b)
+                assert np.array_equal(got, octxs[i].nand_batch(a, b))
+                assert np.array_equal(O.decrypt_bits(got, k[0], p), 1 - (ba & bb))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_caller_streams_and_workspace_growth(keysets):
+    """Device-pointer calls on a torch side stream and on the default stream; batch sizes 3, 700, 5
+    so that the workspace grows and both blind-rotation forms run on one context."""
+    import tfhe_amd
+    import torch
+
+    p, (s0, sr, bk, ks), _ = keysets
+    octx = O.Context(p, bk, ks)
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks) as ctx:
+        side = torch.cuda.Stream()
+        for n, stream in ((3, side), (700, None), (5, torch.cuda.default_stream()), (3, side)):
+            ba, bb, a, b = _enc(p, s0, n, 100 + n)
+            with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+                da = torch.from_numpy(a.view(np.int32)).cuda(non_blocking=False)
+                db = torch.from_numpy(b.view(np.int32)).cuda(non_blocking=False)
+                out = torch.empty_like(da)
+            torch.cuda.synchronize()
+            ctx.nand_device(da, db, out, stream=stream)
+            if stream is None:
+                ctx.synchronize()
+            else:
+                stream.synchronize()
+            got = out.cpu().numpy().view(np.uint32)
+            sample = np.arange(n) if n <= 8 else np.array([0, 1, n // 2, n - 2, n - 1])
+            assert np.array_equal(got[sample], octx.nand_batch(a[sample], b[sample]))
+            assert np.array_equal(O.decrypt_bits(got, s0, p), 1 - (ba & bb))
+
+
+def test_device_pointer_argument_checks(keysets):
+    import tfhe_amd
+    import torch
+
+    p, (s0, sr, bk, ks), _ = keysets
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks) as ctx:
+        a = torch.zeros((2, p.n + 1), dtype=torch.int32, device="cuda")
+        with pytest.raises(ValueError):            # host tensor where a GPU tensor is required
+            ctx.nand_device(a.cpu(), a, a)
+        with pytest.raises(ValueError):            # wrong row length
+            ctx.nand_device(a[:, :-1].contiguous(), a, a)
+        with pytest.raises(ValueError):            # per-gate codes of the wrong length
+            ctx.gate_device(torch.zeros(3, dtype=torch.uint8, device="cuda"), a, a, torch.empty_like(a))
+        lib = tfhe_amd.library()
+        assert lib.tfhe_amd_nand_batch_device(ctx._h, None, None, None, 2, None) == 1   # null arrays
+        assert b"null" in lib.tfhe_amd_last_error()
+        assert lib.tfhe_amd_nand_batch_device(ctx._h, None, None, None, 0, None) == 0   # empty batch: nothing to check
+        assert lib.tfhe_amd_level_batch_device(ctx._h, None, None, None, None, None, 1, 2, None) == 1
