@@ -12,7 +12,7 @@ for f in sorted(glob.glob(f"{src}/*/vm/*counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        key = "blind_rotate_512_kernel" if "blind_rotate_512" in name else "key_switch_kernel" if "key_switch_kernel" in name else None
+        key = "blind_rotate_512_kernel" if "blind_rotate_512_kernel" in name else "key_switch_kernel" if "key_switch_kernel" in name else None
         if key:
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in agg.items():
