@@ -209,6 +209,17 @@ def main():
                 ctx.synchronize()
                 dt = (time.perf_counter() - t0) / reps
                 extra[f"batch_{g_small}"] = {"ms": dt * 1e3, "gates_per_s": g_small / dt}
+            # the whole 65,536-gate configuration on this one GPU (8 x the timed batch)
+            g_big = 65536
+            a8, b8 = a.repeat(g_big // G + 1, 1)[:g_big].contiguous(), b.repeat(g_big // G + 1, 1)[:g_big].contiguous()
+            out8 = torch.empty_like(a8)
+            ctx.nand_device(a8, b8, out8); ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.nand_device(a8, b8, out8)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            extra[f"batch_{g_big}"] = {"ms": dt * 1e3, "gates_per_s": g_big / dt}
+            del a8, b8, out8
             line["other_batches"] = extra
             line["single_gate_latency_ms"] = extra["batch_1"]["ms"]
         if world == 1:
