@@ -81,6 +81,26 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
                         unsigned flags, tfhe_amd_ctx** out);
 void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx);
 
+/* Evaluation-key generation on the GPU: HomNAND::make_evaluate_key (reference src/hom_nand.hpp:56-64),
+ * i.e. TRGSW::make_bk (src/trgsw.hpp:61-82,119-129) and TLWEKeySwitching::make_ks
+ * (src/tlwe_key_switching.hpp:26-45).  s_lv0: [n] bytes 0/1 (SecretKey::tlwe_lv0_s); s_ring:
+ * [K][N] bytes 0/1 (SecretKey::trlwe_s), both in HOST memory.  alpha_lv0 / alpha_lv1: noise standard
+ * deviations of the lv0 TLWE and of the ring (reference src/tlwe.hpp:13, src/trlwe.hpp:12).  Masks
+ * and noise come from a counter-based generator keyed by `seed`: the result is a pure function of
+ * (secret key, seed).  The reference draws from std::random_device and cannot be reproduced, so
+ * generated keys are checked through their decryption, not against reference bytes.
+ *   _keygen:        raw keys to HOST arrays bk / ks (either may be NULL)
+ *   _keygen_device: raw keys to DEVICE arrays on GPU `device`, synchronised before returning
+ *   _ctx_create_from_secret: keys generated on the GPU and turned into a context without
+ *                   ever leaving it */
+int tfhe_amd_keygen(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
+                    double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks);
+int tfhe_amd_keygen_device(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
+                           double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks, void* stream);
+int tfhe_amd_ctx_create_from_secret(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring,
+                                    double alpha_lv0, double alpha_lv1, uint64_t seed, int device, unsigned flags,
+                                    tfhe_amd_ctx** out);
+
 /* HomNAND::nand over a batch (reference src/hom_nand.hpp:74-81): out[g] = NAND(a[g], b[g]).
  * a, b, out: [n_gates][n+1] in HOST memory.  Synchronous. */
 int tfhe_amd_nand_batch(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n_gates);

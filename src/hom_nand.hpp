@@ -62,6 +62,33 @@ public:
         return evaluate_key;
     }
 
+    // make_evaluate_key with the encryptions done on the GPU (tfhe_amd_keygen): same key structure,
+    // masks and noise from a counter-based generator keyed by `seed`.  Not in the reference, whose
+    // make_evaluate_key takes seconds of host time per key set.
+    EvaluateKey make_evaluate_key_gpu(const SecretKey& secret_key, uint64_t seed) {
+        std::vector<uint8_t> s0((size_t)N_LV0), sr((size_t)K * N);
+        for (int i = 0; i < N_LV0; i++) s0[i] = secret_key.tlwe_lv0_s[i] ? 1 : 0;
+        for (int k = 0; k < K; k++)
+            for (int j = 0; j < N; j++) sr[(size_t)k * N + j] = secret_key.trlwe_s[k][j] ? 1 : 0;
+        const tfhe_amd_params p = params();
+        std::vector<uint32_t> bk(tfhe_amd_bk_words(&p)), ks(tfhe_amd_ks_words(&p));
+        gpu::check(tfhe_amd_keygen(&p, s0.data(), sr.data(), TLWELv0Parameter::ALPHA, TRLWEParameter::ALPHA, seed,
+                                   gpu::device(), bk.data(), ks.data()),
+                   "make_evaluate_key_gpu");
+        EvaluateKey ek;
+        const uint32_t* src = bk.data();
+        for (int i = 0; i < N_LV0; i++)
+            for (int r = 0; r < (K + 1) * L; r++)
+                for (int c = 0; c <= K; c++)
+                    for (int j = 0; j < N; j++) ek.bk[i][r][c][j] = TorusValue::from_raw_value(*src++);
+        src = ks.data();
+        for (int i = 0; i < N_LV1; i++)
+            for (int m = 0; m < T; m++)
+                for (int o = 0; o < (1 << BASE_BIT); o++)
+                    for (int w = 0; w <= N_LV0; w++) ek.ks[i][m][o][w] = TorusValue::from_raw_value(*src++);
+        return ek;
+    }
+
     Cipher encrypt(bool m, const SecretKey& secret_key) {
         return tlwe_lv0.encrypt_single_binary(m, secret_key.tlwe_lv0_s);
     }

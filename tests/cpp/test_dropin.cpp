@@ -249,6 +249,19 @@ static void test_other_gates() {  // not in the reference: truth tables of the o
     }
 }
 
+static void test_gpu_keygen() {  // make_evaluate_key_gpu: not in the reference
+    HomNAND<> h(5);
+    auto sk = h.generate_secret_key();
+    auto ek = h.make_evaluate_key_gpu(sk, 99);
+    for (int t = 0; t < 4; t++) {
+        const bool x = t & 1, y = t & 2;
+        CHECK(h.decrypt(h.nand(h.encrypt(x, sk), h.encrypt(y, sk), ek), sk) == !(x && y));
+    }
+    auto ek2 = h.make_evaluate_key_gpu(sk, 99);
+    CHECK(ek2.bk[3][1][2] == ek.bk[3][1][2]);
+    CHECK(ek2.ks[7][2][1] == ek.ks[7][2][1]);
+}
+
 struct RingN1024 { constexpr static int N = 1024; constexpr static int K = 1; constexpr static double ALPHA = 2.9802322387695312e-08; };
 struct Lv1N1024 { constexpr static int N = 1024; constexpr static double ALPHA = 2.9802322387695312e-08; };
 struct Gsw1024 { constexpr static int K = 1; constexpr static int BG_BIT = 8; constexpr static int L = 3; };
@@ -272,6 +285,7 @@ static void run_gpu() {
     test_key_switching();
     test_hom_nand();
     test_other_gates();
+    test_gpu_keygen();
     test_hom_nand_other_ring();
     std::puts("gpu group ok");
 }

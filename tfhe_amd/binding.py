@@ -84,6 +84,10 @@ def library():
     lib.tfhe_amd_ks_words.argtypes = [pp]
     lib.tfhe_amd_ks_words.restype = sz
     lib.tfhe_amd_ctx_create.argtypes = [pp, vp, vp, i32, C.c_uint, C.POINTER(vp)]
+    lib.tfhe_amd_keygen.argtypes = [pp, vp, vp, C.c_double, C.c_double, C.c_uint64, i32, vp, vp]
+    lib.tfhe_amd_keygen_device.argtypes = [pp, vp, vp, C.c_double, C.c_double, C.c_uint64, i32, vp, vp, vp]
+    lib.tfhe_amd_ctx_create_from_secret.argtypes = [pp, vp, vp, C.c_double, C.c_double, C.c_uint64, i32, C.c_uint,
+                                                    C.POINTER(vp)]
     lib.tfhe_amd_ctx_destroy.argtypes = [vp]
     lib.tfhe_amd_ctx_destroy.restype = None
     lib.tfhe_amd_nand_batch.argtypes = [vp, vp, vp, vp, sz]
@@ -189,6 +193,19 @@ class Context:
                 return x.ctypes.data_as(C.c_void_p)
             bk_p, ks_p = host(bk, bk_words), host(ks, ks_words)
         _check(lib.tfhe_amd_ctx_create(C.byref(params), bk_p, ks_p, self.device, flags, C.byref(self._h)))
+
+    @classmethod
+    def from_secret(cls, params, s_lv0, s_ring, alpha_lv0, alpha_lv1, seed, device=0, form=None):
+        """Evaluation keys generated on the GPU from a secret key (what make_evaluate_key does in
+        the reference, src/hom_nand.hpp:56-64) and kept there.  s_lv0: [n] 0/1, s_ring: [K, N] 0/1."""
+        s0, sr = _secret_bytes(params, s_lv0, s_ring)
+        self = cls.__new__(cls)
+        self.params, self.device, self._h = params, int(device), C.c_void_p()
+        flags = {None: 0, 'latency': cls.LATENCY_FORM, 'throughput': cls.THROUGHPUT_FORM}[form]
+        _check(library().tfhe_amd_ctx_create_from_secret(
+            C.byref(params), s0.ctypes.data_as(C.c_void_p), sr.ctypes.data_as(C.c_void_p), float(alpha_lv0),
+            float(alpha_lv1), int(seed), self.device, flags, C.byref(self._h)))
+        return self
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -380,6 +397,29 @@ class Context:
         br, ks, n = C.c_double(), C.c_double(), C.c_int64()
         _check(library().tfhe_amd_ctx_timing(self._h, C.byref(br), C.byref(ks), C.byref(n)))
         return br.value, ks.value, n.value
+
+
+def _secret_bytes(params, s_lv0, s_ring):
+    s0 = np.ascontiguousarray(s_lv0, dtype=np.uint8).reshape(-1)
+    sr = np.ascontiguousarray(s_ring, dtype=np.uint8).reshape(-1)
+    if s0.size != params.n or sr.size != params.K * params.N:
+        raise ValueError("secret key sizes do not match the parameter set")
+    if s0.max(initial=0) > 1 or sr.max(initial=0) > 1:
+        raise ValueError("secret keys are binary")
+    return s0, sr
+
+
+def keygen(params, s_lv0, s_ring, alpha_lv0, alpha_lv1, seed, device=0, want_bk=True, want_ks=True):
+    """(bk, ks) as host arrays, generated on the GPU (reference src/trgsw.hpp:119-129,
+    src/tlwe_key_switching.hpp:26-45).  A key that is not wanted comes back as None."""
+    s0, sr = _secret_bytes(params, s_lv0, s_ring)
+    bk = np.empty(params.bk_shape(), dtype=np.uint32) if want_bk else None
+    ks = np.empty(params.ks_shape(), dtype=np.uint32) if want_ks else None
+    _check(library().tfhe_amd_keygen(C.byref(params), s0.ctypes.data_as(C.c_void_p), sr.ctypes.data_as(C.c_void_p),
+                                     float(alpha_lv0), float(alpha_lv1), int(seed), int(device),
+                                     bk.ctypes.data_as(C.c_void_p) if want_bk else None,
+                                     ks.ctypes.data_as(C.c_void_p) if want_ks else None))
+    return bk, ks
 
 
 def external_product(params, trgsw, trlwe, device=0):

@@ -465,6 +465,80 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     return TFHE_AMD_OK;
 }
 
+int tfhe_amd_keygen_device(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
+                           double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks, void* stream) {
+    if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
+    if (!s_lv0 || !s_ring) return fail(TFHE_AMD_ERR_ARGUMENT, "null secret key");
+    if (!bk && !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "both key pointers are null");
+    if (!(alpha_lv0 >= 0.0 && alpha_lv0 < 0.5 && alpha_lv1 >= 0.0 && alpha_lv1 < 0.5))
+        return fail(TFHE_AMD_ERR_ARGUMENT, "noise parameters must lie in [0, 0.5)");
+    if (p->N > 4096) return fail(TFHE_AMD_ERR_UNSUPPORTED, "ring too large for the key generation kernel");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = stream == TFHE_AMD_DEFAULT_STREAM ? nullptr : (hipStream_t)stream;
+    const size_t ring = (size_t)p->K * p->N;
+    DevBuf d_s0, d_sr;
+    HIP_TRY(d_s0.alloc((size_t)p->n));
+    HIP_TRY(d_sr.alloc(ring));
+    HIP_TRY(hipMemcpyAsync(d_s0.p, s_lv0, (size_t)p->n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_sr.p, s_ring, ring, hipMemcpyHostToDevice, s));
+    if (bk)
+        HIP_TRY(launch_keygen_bk(bk, d_s0.as<uint8_t>(), d_sr.as<uint8_t>(), p->n, p->N, p->K, p->L, p->bg_bit, alpha_lv1,
+                                 seed, s));
+    if (ks)
+        HIP_TRY(launch_keygen_ks(ks, d_s0.as<uint8_t>(), d_sr.as<uint8_t>(), p->n, p->N * p->K, p->T, p->base_bit,
+                                 alpha_lv0, seed, s));
+    HIP_TRY(hipStreamSynchronize(s));  // the secret-key copies are freed on return
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_keygen(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
+                    double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks) {
+    if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
+    if (!bk && !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "both key pointers are null");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
+    const size_t bk_words = tfhe_amd_bk_words(p), ks_words = tfhe_amd_ks_words(p);
+    DevBuf d_bk, d_ks;
+    if (bk) HIP_TRY(d_bk.alloc(bk_words * sizeof(uint32_t)));
+    if (ks) HIP_TRY(d_ks.alloc(ks_words * sizeof(uint32_t)));
+    int rc = tfhe_amd_keygen_device(p, s_lv0, s_ring, alpha_lv0, alpha_lv1, seed, device, bk ? d_bk.as<uint32_t>() : nullptr,
+                                    ks ? d_ks.as<uint32_t>() : nullptr, TFHE_AMD_DEFAULT_STREAM);
+    if (rc) return rc;
+    if (bk) HIP_TRY(hipMemcpy(bk, d_bk.p, bk_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (ks) HIP_TRY(hipMemcpy(ks, d_ks.p, ks_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_ctx_create_from_secret(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring,
+                                    double alpha_lv0, double alpha_lv1, uint64_t seed, int device, unsigned flags,
+                                    tfhe_amd_ctx** out) {
+    if (!out) return fail(TFHE_AMD_ERR_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
+    int rc = tfhe_amd_params_supported(p);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
+    DevBuf d_bk, d_ks;
+    HIP_TRY(d_bk.alloc(tfhe_amd_bk_words(p) * sizeof(uint32_t)));
+    HIP_TRY(d_ks.alloc(tfhe_amd_ks_words(p) * sizeof(uint32_t)));
+    rc = tfhe_amd_keygen_device(p, s_lv0, s_ring, alpha_lv0, alpha_lv1, seed, device, d_bk.as<uint32_t>(),
+                                d_ks.as<uint32_t>(), TFHE_AMD_DEFAULT_STREAM);
+    if (rc) return rc;
+    return tfhe_amd_ctx_create(p, d_bk.as<uint32_t>(), d_ks.as<uint32_t>(), device, flags | TFHE_AMD_CTX_KEYS_ON_DEVICE,
+                               out);
+}
+
 void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);

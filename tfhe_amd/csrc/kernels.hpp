@@ -25,6 +25,11 @@ hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint
 hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
                                    const uint32_t* tv, uint32_t* out, int n_gates, int n, int K, int L, int extract,
                                    int form, hipStream_t stream);
+// evaluation-key generation (keygen_kernels.hip): raw keys in the flat layouts of tfhe_amd.h, device memory
+hipError_t launch_keygen_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, int n, int N, int K, int L,
+                            int bg_bit, double alpha, uint64_t seed, hipStream_t stream);
+hipError_t launch_keygen_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_lv1, int n, int nlv1, int T, int bb,
+                            double alpha, uint64_t seed, hipStream_t stream);
 // exact O(N^2) kernels for any parameter set (generic_kernels.hip)
 bool generic_has_kernel(int N, int K, int L);
 hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
