@@ -55,3 +55,24 @@ def test_argument_errors_without_gpu():
     assert lib.tfhe_amd_nand_batch(None, None, None, None, 4) == 1
     with pytest.raises(ValueError):
         tfhe_amd.Context(p, np.zeros(3, np.uint32), np.zeros(3, np.uint32))
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/tfhe_amd.h compiles as strict C99 (no C++ or torch type crosses the boundary) and a C
+    program that takes the address of every declared entry point links against the library."""
+    import subprocess
+
+    root = HEADER.parent.parent
+    src = tmp_path / "abi.c"
+    refs = "\n".join(f"    keep[{i}] = (void (*)(void))&{name};" for i, name in enumerate(declared_functions()))
+    src.write_text('#include "tfhe_amd.h"\n#include <stdio.h>\nint main(void) {\n'
+                   f"    void (*keep[{len(declared_functions())}])(void);\n{refs}\n"
+                   "    tfhe_amd_params p;\n    tfhe_amd_params_default(&p);\n"
+                   '    printf("%d %s %d\\n", p.N, tfhe_amd_version(), keep[0] != 0);\n    return 0;\n}\n')
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", str(root / "include"), str(src),
+                        "-L", str(root / "tfhe_amd"), "-ltfhe_amd", f"-Wl,-rpath,{root / 'tfhe_amd'}", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split()[0] == "512", out.stdout + out.stderr

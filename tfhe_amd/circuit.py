@@ -163,9 +163,13 @@ class DeviceBackend:
     def _stream(self):
         return self.torch.cuda.current_stream()
 
+    def _codes(self, ops, device):
+        if hasattr(ops, "data_ptr"):
+            return ops
+        return self.torch.tensor(np.asarray(ops, dtype=np.uint8), device=device)
+
     def gates(self, ops, a, b):
-        ops_t = self.torch.tensor(np.asarray(ops, dtype=np.uint8), device=a.device)
-        return self.ctx.gate_device(ops_t, a, b, self.torch.empty_like(a), stream=self._stream())
+        return self.ctx.gate_device(self._codes(ops, a.device), a, b, self.torch.empty_like(a), stream=self._stream())
 
     def not_(self, a):
         return self.ctx.not_device(a, self.torch.empty_like(a), stream=self._stream())
@@ -175,7 +179,7 @@ class DeviceBackend:
 
     def level(self, ops, a, b, x0, n_mux):
         """Two-input gates (codes `ops`) followed by n_mux MUX gates, one launch."""
-        ops_t = self.torch.tensor(np.asarray(ops, dtype=np.uint8), device=a.device) if len(ops) else None
+        ops_t = self._codes(ops, a.device) if len(ops) else None
         return self.ctx.level_device(ops_t, a, b, x0, self.torch.empty_like(a), n_mux, stream=self._stream())
 
 
@@ -186,61 +190,96 @@ class _NandOnly:
         self.fn = fn
 
     def gates(self, ops, a, b):
-        if any(int(o) != 0 for o in ops):
+        if bool((ops != 0).any()):
             raise ValueError("this backend evaluates NAND gates only")
         return self.fn(a, b)
 
 
-def evaluate(gates, wires, backend, levels=None):
-    """Evaluates the netlist in place on `wires` ([n_wires, n+1] numpy uint32, or a torch GPU
-    tensor with a DeviceBackend).  `backend`: a HostBackend / DeviceBackend (or any object with
-    gates(ops, a, b), not_(a), mux(sel, x1, x0)), or a callable nand_batch(a_rows, b_rows) ->
-    out_rows for NAND-only netlists.  Returns the number of levels executed."""
-    if callable(backend) and not hasattr(backend, "gates"):
-        backend = _NandOnly(backend)
-    if levels is None:
-        levels = levelize(gates, wires.shape[0])
-    norm = [normalize(g) for g in gates]
-    is_torch = not isinstance(wires, np.ndarray)
-    if is_torch:
+class Plan:
+    """A levelised netlist with its per-level operand and result index arrays prepared once, so
+    that evaluating the circuit again (other inputs, same netlist) builds nothing and, with GPU
+    tensors, copies no index array to the device."""
+
+    def __init__(self, gates, n_wires, levels=None):
+        self.n_wires = n_wires
+        norm = [normalize(g) for g in gates]
+        self.levels = levelize(gates, n_wires) if levels is None else levels
+        self.steps = []
+        for lv in self.levels:
+            two = [g for g in lv if norm[g][1] in GATES]
+            nots = [g for g in lv if norm[g][1] == "not"]
+            muxes = [g for g in lv if norm[g][1] == "mux"]
+            idx = lambda gs, k: np.array([norm[g][2][k] for g in gs], dtype=np.int64)  # noqa: E731
+            outs = lambda gs: np.array([norm[g][0] for g in gs], dtype=np.int64)  # noqa: E731
+            self.steps.append({
+                "ops": np.array([GATES[norm[g][1]] for g in two], dtype=np.uint8),
+                "two": (idx(two, 0), idx(two, 1), outs(two)),
+                "not": (idx(nots, 0), outs(nots)),
+                "mux": (idx(muxes, 0), idx(muxes, 1), idx(muxes, 2), outs(muxes)),
+                # two-input gates followed by MUXes, for backends that take a whole level at once
+                "both": (np.concatenate([idx(two, 0), idx(muxes, 0)]), np.concatenate([idx(two, 1), idx(muxes, 1)]),
+                         np.concatenate([outs(two), outs(muxes)])),
+            })
+        self._device_steps = {}
+
+    def on(self, device):
+        """The same arrays as torch tensors on `device` (cached)."""
         import torch
 
+        key = str(device)
+        if key not in self._device_steps:
+            conv = lambda v: torch.from_numpy(v).to(device)  # noqa: E731
+            self._device_steps[key] = [{k: (conv(v) if isinstance(v, np.ndarray) else tuple(conv(x) for x in v))
+                                        for k, v in st.items()} for st in self.steps]
+        return self._device_steps[key]
+
+
+def evaluate(gates, wires, backend, levels=None, plan=None):
+    """Evaluates the netlist in place on `wires` ([n_wires, n+1] numpy uint32, or a torch GPU
+    tensor with a DeviceBackend).  `backend`: a HostBackend / DeviceBackend (or any object with
+    gates(ops, a, b), not_(a), mux(sel, x1, x0) and optionally level(ops, a, b, x0, n_mux)), or a
+    callable nand_batch(a_rows, b_rows) -> out_rows for NAND-only netlists.  `plan`: a Plan of
+    the same netlist, to reuse its index arrays across calls.  Returns the number of levels."""
+    if callable(backend) and not hasattr(backend, "gates"):
+        backend = _NandOnly(backend)
+    if plan is None:
+        plan = Plan(gates, wires.shape[0], levels)
+    is_torch = not isinstance(wires, np.ndarray)
+    if is_torch:
+        steps = plan.on(wires.device)
+
         def rows(idx):
-            return wires.index_select(0, torch.tensor(idx, dtype=torch.long, device=wires.device)).contiguous()
+            return wires.index_select(0, idx)
 
         def store(idx, val):
-            wires.index_copy_(0, torch.tensor(idx, dtype=torch.long, device=wires.device), val)
+            wires.index_copy_(0, idx, val)
     else:
+        steps = plan.steps
+
         def rows(idx):
             return np.ascontiguousarray(wires[idx])
 
         def store(idx, val):
             wires[idx] = val
 
-    for lv in levels:
-        two = [g for g in lv if norm[g][1] in GATES]
-        nots = [g for g in lv if norm[g][1] == "not"]
-        muxes = [g for g in lv if norm[g][1] == "mux"]
+    for st in steps:
+        n_two, n_not, n_mux = len(st["ops"]), len(st["not"][0]), len(st["mux"][0])
         # all operands are read before any result of the level is stored
         results = []
-        if two and muxes and hasattr(backend, "level"):
+        if n_two and n_mux and hasattr(backend, "level"):
             # both kinds in one call: the level then costs one blind-rotation latency
-            order = two + muxes
-            out = backend.level([GATES[norm[g][1]] for g in two], rows([norm[g][2][0] for g in order]),
-                                rows([norm[g][2][1] for g in order]), rows([norm[g][2][2] for g in muxes]),
-                                len(muxes))
-            results.append(([norm[g][0] for g in order], out))
-            two, muxes = [], []
-        if two:
-            out = backend.gates([GATES[norm[g][1]] for g in two], rows([norm[g][2][0] for g in two]),
-                                rows([norm[g][2][1] for g in two]))
-            results.append(([norm[g][0] for g in two], out))
-        if nots:
-            results.append(([norm[g][0] for g in nots], backend.not_(rows([norm[g][2][0] for g in nots]))))
-        if muxes:
-            out = backend.mux(rows([norm[g][2][0] for g in muxes]), rows([norm[g][2][1] for g in muxes]),
-                              rows([norm[g][2][2] for g in muxes]))
-            results.append(([norm[g][0] for g in muxes], out))
+            ia, ib, o = st["both"]
+            results.append((o, backend.level(st["ops"], rows(ia), rows(ib), rows(st["mux"][2]), n_mux)))
+            n_two = n_mux = 0
+        if n_two:
+            ia, ib, o = st["two"]
+            results.append((o, backend.gates(st["ops"], rows(ia), rows(ib))))
+        if n_not:
+            ia, o = st["not"]
+            results.append((o, backend.not_(rows(ia))))
+        if n_mux:
+            isel, i1, i0, o = st["mux"]
+            results.append((o, backend.mux(rows(isel), rows(i1), rows(i0))))
         for idx, val in results:
             store(idx, val)
-    return len(levels)
+    return len(plan.levels)

@@ -19,12 +19,13 @@ ctx = tfhe_amd.Context(p, bk, ks)
 backend = C.DeviceBackend(ctx)
 for name, build in (("NAND-only", C.ripple_carry_adder), ("XOR/MUX", C.mux_adder)):
     gates, n_wires, a, b, zero, sums, cout = build(32)
-    levels = C.levelize(gates, n_wires)
+    plan = C.Plan(gates, n_wires)
+    levels = plan.levels
     dw = torch.randint(-2**31, 2**31 - 1, (n_wires, p.n1), dtype=torch.int32, device="cuda")
-    C.evaluate(gates, dw, backend, levels)
+    C.evaluate(gates, dw, backend, plan=plan)
     torch.cuda.synchronize()
     t0 = time.time()
-    C.evaluate(gates, dw, backend, levels)
+    C.evaluate(gates, dw, backend, plan=plan)
     torch.cuda.synchronize()
     dt = time.time() - t0
     print(f"32-bit adder, {name}: {len(gates)} gates in {len(levels)} levels: {dt*1e3:.1f} ms "
