@@ -115,3 +115,35 @@ def test_device_pointer_argument_checks(keysets):
         assert b"null" in lib.tfhe_amd_last_error()
         assert lib.tfhe_amd_nand_batch_device(ctx._h, None, None, None, 0, None) == 0   # empty batch: nothing to check
         assert lib.tfhe_amd_level_batch_device(ctx._h, None, None, None, None, None, 1, 2, None) == 1
+
+
+def test_two_host_threads_each_with_its_own_context(keysets):
+    """One context per host thread is the supported way to call from several threads; the library
+    keeps its error text per thread and its device state per context."""
+    import threading
+
+    import tfhe_amd
+
+    p, k1, k2 = keysets
+    results, errors = {}, []
+
+    def work(tag, k, seed):
+        try:
+            with tfhe_amd.Context(tfhe_amd.params_default(), k[2], k[3]) as ctx:
+                ba, bb, a, b = _enc(p, k[0], 40, seed)
+                outs = [ctx.nand(a, b) for _ in range(3)]
+                assert all(np.array_equal(outs[0], o) for o in outs[1:])
+                results[tag] = (ba, bb, a, b, outs[0])
+        except Exception as e:  # surfaced in the main thread
+            errors.append((tag, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i, k, 300 + i)) for i, k in enumerate((k1, k2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for i, k in enumerate((k1, k2)):
+        ba, bb, a, b, got = results[i]
+        assert np.array_equal(O.decrypt_bits(got, k[0], p), 1 - (ba & bb))
+        assert np.array_equal(got[:4], O.Context(p, k[2], k[3]).nand_batch(a[:4], b[:4]))
