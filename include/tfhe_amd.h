@@ -6,7 +6,8 @@
  * and the functions under it, bind to when evaluation is moved to the GPU.  All pointers are
  * plain arrays of uint32_t torus words in the flat layouts described next; no C++ or torch
  * type crosses this boundary.  Every call returns an int status (0 = success) and never
- * throws.  A context may be used from one host thread at a time.
+ * throws.  A context may be used from one host thread at a time; calls enqueued on different
+ * streams through one context share its workspace and are ordered one behind the other.
  *
  * Flat layouts (row-major):
  *   lv0 ciphertext    [n+1]                      = [b, a_0 .. a_{n-1}]   (reference src/hom_nand.hpp:43,

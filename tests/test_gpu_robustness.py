@@ -147,3 +147,30 @@ def test_two_host_threads_each_with_its_own_context(keysets):
         ba, bb, a, b, got = results[i]
         assert np.array_equal(O.decrypt_bits(got, k[0], p), 1 - (ba & bb))
         assert np.array_equal(got[:4], O.Context(p, k[2], k[3]).nand_batch(a[:4], b[:4]))
+
+
+def test_back_to_back_calls_on_two_streams_share_the_workspace_safely(keysets):
+    """Two device-pointer calls on different streams with no synchronisation between them: the
+    second must not overwrite the context's workspace while the first still reads it."""
+    import tfhe_amd
+    import torch
+
+    p, (s0, sr, bk, ks), _ = keysets
+    octx = O.Context(p, bk, ks)
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks) as ctx:
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        ba1, bb1, a1, b1 = _enc(p, s0, 2300, 901)
+        ba2, bb2, a2, b2 = _enc(p, s0, 600, 902)
+        d = [torch.from_numpy(x.view(np.int32)).cuda() for x in (a1, b1, a2, b2)]
+        o1, o2 = torch.empty_like(d[0]), torch.empty_like(d[2])
+        torch.cuda.synchronize()
+        for _ in range(2):
+            ctx.nand_device(d[0], d[1], o1, stream=sa)
+            ctx.nand_device(d[2], d[3], o2, stream=sb)
+        torch.cuda.synchronize()
+        g1, g2 = o1.cpu().numpy().view(np.uint32), o2.cpu().numpy().view(np.uint32)
+        assert np.array_equal(O.decrypt_bits(g1, s0, p), 1 - (ba1 & bb1))
+        assert np.array_equal(O.decrypt_bits(g2, s0, p), 1 - (ba2 & bb2))
+        pick1, pick2 = np.array([0, 1, 1150, 2299]), np.array([0, 299, 599])
+        assert np.array_equal(g1[pick1], octx.nand_batch(a1[pick1], b1[pick1]))
+        assert np.array_equal(g2[pick2], octx.nand_batch(a2[pick2], b2[pick2]))

@@ -77,6 +77,12 @@ struct tfhe_amd_ctx {
     uint32_t* d_c = nullptr;
     uint32_t* d_lv1 = nullptr;
     size_t ws_gates = 0;
+    // The workspace is shared by all calls on this context.  Calls enqueued on different streams
+    // are ordered through this event: every call records it behind its last kernel, and a call on
+    // another stream waits for it before touching the workspace.
+    hipEvent_t ws_done = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
     // staging for the host-pointer entry points
     uint32_t* d_io = nullptr;
     size_t io_words = 0;
@@ -271,6 +277,7 @@ int run_key_switch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t
 int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s,
                   size_t n_mux = 0) {
     hipEvent_t* e = nullptr;
+    // (the combination kernels that fill `c` ran on `s` already, after workspace_acquire)
     if (ctx->timing) {
         if (ctx->ev_count == kTimingRing) {
             int rc = drain_timing(ctx, kTimingRing - 1);
@@ -291,7 +298,19 @@ int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_
         HIP_TRY(hipEventRecord(e[2], s));
         ctx->ev_count++;
     }
+    HIP_TRY(hipEventRecord(ctx->ws_done, s));
+    ctx->ws_stream = s;
+    ctx->ws_used = true;
     return TFHE_AMD_OK;
+}
+
+// Orders a call on stream `s` behind the previous user of the workspace when that one ran on
+// another stream, and grows the workspace (hipFree waits for the device, so no kernel still reads
+// the old buffers).
+int workspace_acquire(tfhe_amd_ctx* ctx, size_t n_rows, hipStream_t s) {
+    if (!ctx->ws_done) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming));
+    if (ctx->ws_used && ctx->ws_stream != s) HIP_TRY(hipStreamWaitEvent(s, ctx->ws_done, 0));
+    return ensure_workspace(ctx, n_rows);
 }
 
 int check_gate_code(int op) {
@@ -544,6 +563,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx) {
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
     void* bufs[] = {ctx->d_tw, ctx->d_bk_ntt, ctx->d_bk_raw, ctx->d_ks, ctx->d_c, ctx->d_lv1, ctx->d_io};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -558,8 +578,9 @@ int tfhe_amd_bootstrap_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
-    return run_bootstrap(ctx, c, out, n_gates, pick_stream(ctx, stream));
+    hipStream_t s = pick_stream(ctx, stream);
+    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
+    return run_bootstrap(ctx, c, out, n_gates, s);
 }
 
 int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
@@ -568,8 +589,8 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
     hipStream_t s = pick_stream(ctx, stream);
+    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
     HIP_TRY(launch_nand_combine(ctx->d_c, a, b, n_gates, ctx->p.n + 1, s));
     return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
 }
@@ -580,8 +601,8 @@ int tfhe_amd_gate_batch_device(tfhe_amd_ctx* ctx, int op, const uint32_t* a, con
     if (rc || (rc = check_gate_code(op)) || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
     hipStream_t s = pick_stream(ctx, stream);
+    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
     HIP_TRY(launch_gate_combine(ctx->d_c, a, b, nullptr, op, n_gates, ctx->p.n + 1, s));
     return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
 }
@@ -592,8 +613,8 @@ int tfhe_amd_gates_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uin
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    if ((rc = ensure_workspace(ctx, n_gates))) return rc;
     hipStream_t s = pick_stream(ctx, stream);
+    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
     HIP_TRY(launch_gate_combine(ctx->d_c, a, b, ops, 0, n_gates, ctx->p.n + 1, s));
     return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
 }
@@ -614,8 +635,8 @@ int tfhe_amd_level_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uin
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     DeviceGuard guard(ctx->device);
-    if ((rc = ensure_workspace(ctx, n_gates + n_mux))) return rc;
     hipStream_t s = pick_stream(ctx, stream);
+    if ((rc = workspace_acquire(ctx, n_gates + n_mux, s))) return rc;
     const size_t n1 = n1_of(ctx);
     HIP_TRY(launch_gate_combine(ctx->d_c, a, b, ops, 0, n_two, (int)n1, s));
     HIP_TRY(launch_gate_combine(ctx->d_c + n_two * n1, a + n_two * n1, b + n_two * n1, nullptr, TFHE_AMD_GATE_AND,
