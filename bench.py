@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the 1,024-gate and single-gate timings (for clean rocprofv3 kernel averages)")
-    ap.add_argument("--cpu-sample-gates", type=int, default=32)
+    ap.add_argument("--cpu-sample-gates", type=int, default=64)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,6 +197,9 @@ def main():
                                                       "8192 gates; the NTT-domain key (46.9 MB) is re-streamed from the "
                                                       "Infinity Cache once per XCD and wave generation, L2 hit rate 99 %")
                 line["roofline"]["valu_pipe_busy"] = 2 * k.get("valu_active_share_of_wave_cycles", 0.0)
+                # the same kernel against the HBM roofline, to show which of the two binds
+                hbm_gbps = k["hbm_bytes_per_launch"] * (G / 8192.0) / br_avg_s / 1e9
+                line["roofline"]["hbm"] = {"achieved": hbm_gbps, "peak": 8000.0, "unit": "GB/s", "frac": hbm_gbps / 8000.0}
         # the 1,024-gate single-GPU configuration and single-gate latency, measured beside it
         if world == 1 and not args.no_extras:
             extra = {}
