@@ -206,8 +206,101 @@ static inline uint32_t g_to_torus(uint64_t v) {
     return (uint32_t)v;
 }
 
+/* ---- replay of the reference's FFT product (reference src/types.hpp:237-292, fft :152-197) ----
+ * Restated from its definition: fold the N reals into M = N/2 complex numbers (first half real
+ * parts, second half imaginary parts), twist by successive powers of e^(i pi / N) built by
+ * repeated multiplication, an M-point decimation-in-frequency style FFT whose stage i multiplies
+ * the upper half of block j by omega^bitrev(2j) and ends with a bit-reversal permutation,
+ * pointwise product, the same FFT with the omega table reversed from index 1, scale by 1/M, untwist,
+ * and convert each part with the truncating double -> torus rule.  Every floating-point operation
+ * is a plain IEEE double multiply, add or subtract in the reference's order (complex products as
+ * (ac - bd, ad + bc)); libm's cos and sin give the same table as std::polar on the same machine.
+ * Build without -ffast-math and without FMA contraction (the oracle's Makefile does). */
+typedef struct { double re, im; } cplx;
+static inline cplx c_mul(cplx x, cplx y) {
+    const double ac = x.re * y.re, bd = x.im * y.im, ad = x.re * y.im, bc = x.im * y.re;
+    cplx r = { ac - bd, ad + bc };
+    return r;
+}
+static inline cplx c_polar(double theta) { cplx r = { 1.0 * cos(theta), 1.0 * sin(theta) }; return r; }
+
+static void ref_fft(cplx* a, cplx* tmp, int M, const cplx* omega_pow) {
+    int bits = 0;
+    while ((1 << bits) < M) bits++;
+    cplx* cur = a;
+    cplx* nxt = tmp;
+    for (int i = 0; i < bits; i++) {
+        const int span = 1 << (bits - i), half = span >> 1;
+        for (int j = 0; j < (1 << i); j++) {
+            int rev = 0;
+            const int v = j << 1;
+            for (int t = 0; t < bits; t++) if (v & (1 << t)) rev |= 1 << (bits - t - 1);
+            for (int k = 0; k < half; k++) {
+                const cplx even = cur[j * span + k];
+                const cplx odd = c_mul(cur[j * span + k + half], omega_pow[rev]);
+                nxt[j * span + k].re = even.re + odd.re;
+                nxt[j * span + k].im = even.im + odd.im;
+                nxt[j * span + k + half].re = even.re - odd.re;
+                nxt[j * span + k + half].im = even.im - odd.im;
+            }
+        }
+        cplx* sw = cur; cur = nxt; nxt = sw;
+    }
+    for (int i = 0; i < M; i++) {
+        int rev = 0;
+        for (int t = 0; t < bits; t++) if (i & (1 << t)) rev |= 1 << (bits - t - 1);
+        nxt[rev] = cur[i];
+    }
+    if (nxt != a) memcpy(a, nxt, sizeof(cplx) * M);
+}
+
+static void reference_fft_mul(uint32_t* out, const int32_t* d, const uint32_t* b, int N) {
+    const int M = N >> 1;
+    cplx* buf = (cplx*)malloc(sizeof(cplx) * (size_t)M * 5);
+    cplx *lhs = buf, *rhs = buf + M, *tmp = buf + 2 * M, *omega_pow = buf + 3 * M, *prod = buf + 4 * M;
+    for (int i = 0; i < M; i++) {
+        lhs[i].re = (double)d[i];
+        lhs[i].im = (double)d[i + M];
+        rhs[i].re = (double)b[i] / 4294967296.0;       /* operator double: raw / 2^32 */
+        rhs[i].im = (double)b[i + M] / 4294967296.0;
+    }
+    const cplx w = c_polar(M_PI / (M * 2));
+    cplx w_pow = { 1.0, 0.0 };
+    for (int i = 0; i < M; i++) {
+        lhs[i] = c_mul(lhs[i], w_pow);
+        rhs[i] = c_mul(rhs[i], w_pow);
+        w_pow = c_mul(w_pow, w);
+    }
+    const cplx omega = c_polar(-M_PI * 2 / M);
+    omega_pow[0].re = 1.0; omega_pow[0].im = 0.0;
+    for (int i = 0; i < M - 1; i++) omega_pow[i + 1] = c_mul(omega_pow[i], omega);
+    ref_fft(lhs, tmp, M, omega_pow);
+    ref_fft(rhs, tmp, M, omega_pow);
+    for (int i = 0; i < M; i++) prod[i] = c_mul(lhs[i], rhs[i]);
+    for (int i = 1, j = M - 1; i < j; i++, j--) { cplx t = omega_pow[i]; omega_pow[i] = omega_pow[j]; omega_pow[j] = t; }
+    ref_fft(prod, tmp, M, omega_pow);
+    const cplx w_inv = c_polar(-M_PI / (M * 2));
+    cplx w_inv_pow = { 1.0, 0.0 };
+    const double scale = 1. / M;
+    for (int i = 0; i < M; i++) {
+        prod[i].re *= scale;
+        prod[i].im *= scale;
+        prod[i] = c_mul(prod[i], w_inv_pow);
+        w_inv_pow = c_mul(w_inv_pow, w_inv);
+    }
+    for (int i = 0; i < M; i++) {
+        out[i] = tfo_torus_from_double(prod[i].re);
+        out[i + M] = tfo_torus_from_double(prod[i].im);
+    }
+    free(buf);
+}
+
 void tfo_negacyclic_mul(uint32_t* out, const int32_t* d, const uint32_t* b, int N, int mode) {
-    if (mode == TFO_MUL_SCHOOLBOOK) {
+    if (mode == TFO_MUL_REFERENCE_FFT && N >= 32) {  /* below 32 the reference multiplies exactly */
+        reference_fft_mul(out, d, b, N);
+        return;
+    }
+    if (mode == TFO_MUL_SCHOOLBOOK || mode == TFO_MUL_REFERENCE_FFT) {
         memset(out, 0, sizeof(uint32_t) * N);
         tfo_negacyclic_mac_schoolbook(out, d, b, N);
         return;
@@ -231,7 +324,17 @@ void tfo_external_product(uint32_t* out, const uint32_t* trgsw, const uint32_t* 
     int32_t* dec = (int32_t*)malloc(sizeof(int32_t) * (size_t)R * N);
     for (int comp = 0; comp < K1; comp++)
         tfo_decompose(dec + (size_t)comp * L * N, trlwe + (size_t)comp * N, p);
-    if (mode == TFO_MUL_SCHOOLBOOK) {
+    if (mode == TFO_MUL_REFERENCE_FFT && N >= 32) {
+        /* every product rounded on its own, then wrap-around sums (reference src/types.hpp:433-445) */
+        uint32_t* prod = (uint32_t*)malloc(sizeof(uint32_t) * N);
+        memset(out, 0, sizeof(uint32_t) * (size_t)K1 * N);
+        for (int r = 0; r < R; r++)
+            for (int c = 0; c < K1; c++) {
+                reference_fft_mul(prod, dec + (size_t)r * N, trgsw + ((size_t)r * K1 + c) * N, N);
+                for (int i = 0; i < N; i++) out[(size_t)c * N + i] += prod[i];
+            }
+        free(prod);
+    } else if (mode == TFO_MUL_SCHOOLBOOK || mode == TFO_MUL_REFERENCE_FFT) {
         memset(out, 0, sizeof(uint32_t) * (size_t)K1 * N);
         for (int r = 0; r < R; r++)
             for (int c = 0; c < K1; c++)

@@ -44,7 +44,11 @@ typedef struct tfo_params {
     double alpha_lv1; /* ring noise stddev             (reference src/trlwe.hpp:12)  */
 } tfo_params;
 
-enum { TFO_MUL_SCHOOLBOOK = 0, TFO_MUL_NTT = 1 };
+/* Multipliers.  SCHOOLBOOK and NTT are exact and interchangeable.  REFERENCE_FFT replays the
+ * reference's own double-precision FFT product (src/types.hpp:152-197,237-292) operation by
+ * operation, rounding included, so that the whole pipeline can be compared bit for bit with the
+ * compiled reference at ring degrees where that product is inexact (N >= 32). */
+enum { TFO_MUL_SCHOOLBOOK = 0, TFO_MUL_NTT = 1, TFO_MUL_REFERENCE_FFT = 2 };
 
 /* parameter sets */
 void tfo_params_default(tfo_params* p); /* n=636 N=512 K=2 bg=8 L=2 T=5 base=2 */

@@ -55,6 +55,18 @@ def test_oracle_vs_compiled_reference_default_parameters(case):
     _check(p, s0, ba, bb, ours, ref)
 
 
+def test_oracle_with_replayed_fft_equals_the_compiled_reference_bit_for_bit(case):
+    """The oracle with its multiplier swapped for a replay of the reference's FFT product
+    (TFO_MUL_REFERENCE_FFT) reproduces the compiled reference's output ciphertexts exactly, at the
+    default parameters, through all 636 blind-rotation steps and the key switch: everything in the
+    oracle except the multiplier is thereby pinned to the real reference at full size, and the
+    exact multipliers differ from the replayed one only by the reference's own rounding."""
+    p, s0, bk, ks, ba, bb, a, b, ref = case
+    n = 3
+    ours = np.stack([O.nand(a[g], b[g], bk, ks, p, 2) for g in range(n)])
+    assert np.array_equal(ours, ref[:n])
+
+
 @pytest.mark.gpu
 def test_gpu_vs_compiled_reference_default_parameters(case):
     import tfhe_amd
