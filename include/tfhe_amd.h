@@ -71,7 +71,14 @@ enum {
      * (throughput) and one gate per workgroup (latency).  By default batches of at most 512 gates
      * take the latency form; these flags pin one form. */
     TFHE_AMD_CTX_LATENCY_FORM = 4,
-    TFHE_AMD_CTX_THROUGHPUT_FORM = 8
+    TFHE_AMD_CTX_THROUGHPUT_FORM = 8,
+    /* Verification mode.  The reference multiplies polynomials with a double-precision FFT
+     * (src/types.hpp:237-292) whose result is the exact product or one unit lower; by default this
+     * library returns the exact product.  With this flag the blind rotation replays the reference's
+     * FFT operation by operation, rounding included, and the output ciphertexts are bit-identical to
+     * those of the reference compiled without FMA contraction (g++ -O2 on x86-64).  Ring degrees
+     * 32 .. 1024; much slower than the default path. */
+    TFHE_AMD_CTX_REFERENCE_FFT = 16
 };
 
 /* Replaces holding an EvaluateKey (reference src/hom_nand.hpp:36-42): uploads the keys to GPU

@@ -76,3 +76,20 @@ def test_gpu_vs_compiled_reference_default_parameters(case):
         ours = ctx.nand(a, b)
     _check(p, s0, ba, bb, ours, ref)
     assert np.array_equal(ours, O.Context(p, bk, ks).nand_batch(a, b))
+
+
+@pytest.mark.gpu
+def test_gpu_reference_fft_mode_equals_the_compiled_reference_bit_for_bit(case):
+    """TFHE_AMD_CTX_REFERENCE_FFT: the GPU replays the reference's FFT product, and its NAND output
+    equals the compiled reference's ciphertexts word for word (all 8 gates, 637 words each)."""
+    import tfhe_amd
+
+    p, s0, bk, ks, ba, bb, a, b, ref = case
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks, reference_fft=True) as ctx:
+        got = ctx.nand(a, b)
+        c = np.stack([O.nand_combine(x, y, p) for x, y in zip(a[:2], b[:2])])
+        acc = ctx.blind_rotate(c)
+    assert np.array_equal(got, ref)
+    # and stage by stage against the oracle's replay
+    for g in range(2):
+        assert np.array_equal(acc[g], O.blind_rotate(c[g], bk, p, 2))

@@ -164,19 +164,22 @@ class Context:
     """Device-resident evaluation key: what holding a HomNAND::EvaluateKey
     (reference src/hom_nand.hpp:36-42) becomes on the GPU."""
 
-    KEYS_ON_DEVICE, GENERIC_KERNELS, LATENCY_FORM, THROUGHPUT_FORM = 1, 2, 4, 8
+    KEYS_ON_DEVICE, GENERIC_KERNELS, LATENCY_FORM, THROUGHPUT_FORM, REFERENCE_FFT = 1, 2, 4, 8, 16
 
-    def __init__(self, params, bk, ks, device=0, keys_on_device=False, generic_kernels=False, form=None):
+    def __init__(self, params, bk, ks, device=0, keys_on_device=False, generic_kernels=False, form=None,
+                 reference_fft=False):
         """bk / ks: numpy uint32 arrays (host) or 32-bit torch GPU tensors (keys_on_device);
         either may be None.  generic_kernels: use the parameter-generic exact O(N^2) kernels
         even where a specialised NTT kernel exists.  form: None (by batch size), 'latency' or
-        'throughput' for the specialised blind rotation."""
+'throughput' for the specialised blind rotation.  reference_fft: verification mode, products
+        through a replay of the reference's FFT (output bit-identical to the compiled reference)."""
         lib = library()
         self.params = params
         self.device = int(device)
         self._h = C.c_void_p()
         flags = (self.KEYS_ON_DEVICE if keys_on_device else 0) | (self.GENERIC_KERNELS if generic_kernels else 0)
         flags |= {None: 0, 'latency': self.LATENCY_FORM, 'throughput': self.THROUGHPUT_FORM}[form]
+        flags |= self.REFERENCE_FFT if reference_fft else 0
         bk_words, ks_words = lib.tfhe_amd_bk_words(C.byref(params)), lib.tfhe_amd_ks_words(C.byref(params))
         if keys_on_device:
             bk_p = _dev_ptr(bk, bk_words) if bk is not None else None

@@ -3,6 +3,7 @@
 // generic_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -64,6 +65,8 @@ struct tfhe_amd_ctx {
     int device = 0;
     bool fast = false;             // specialised NTT kernels (N = 512, K = 2, L = 2, 8-bit gadget)
     bool wg = false;               // workgroup-cooperative NTT kernels (N = 2048 set)
+    bool replica = false;          // products through a replay of the reference's FFT (verification)
+    d2* d_spec = nullptr;          // replica: key spectra
     int parts = 1, shift = 0;      // key split of the wg path
     NttUniform u{};
     d2* d_tw = nullptr;
@@ -160,6 +163,47 @@ std::vector<double> build_tw_block_512(const TwiddleSet& t) {
     return blk;
 }
 
+// Power tables of the reference's FFT product for ring degree N (M = N / 2), as the reference builds
+// them (src/types.hpp:257-268,276-283): [0] twist powers w^i, w = e^(i pi / N), by repeated
+// multiplication; [1] omega^i, omega = e^(-2 pi i / M), by repeated multiplication; [2] untwist
+// powers; [3] the omega table with entries 1 .. M-1 reversed.  cos and sin are libm's, as in
+// std::polar; the arguments are volatile so that they are evaluated at run time by that libm.
+std::vector<double> build_replica_tables(int N) {
+    const int M = N / 2;
+    std::vector<double> t((size_t)4 * M * 2);
+    auto cmul = [](double xr, double xi, double yr, double yi, double& rr, double& ri) {
+        const double ac = xr * yr, bd = xi * yi, ad = xr * yi, bc = xi * yr;
+        rr = ac - bd;
+        ri = ad + bc;
+    };
+    auto polar = [](double theta, double& r, double& i) {
+        volatile double th = theta;
+        r = 1.0 * std::cos(th);
+        i = 1.0 * std::sin(th);
+    };
+    auto fill_powers = [&](int section, double theta) {
+        double wr, wi, pr = 1.0, pi = 0.0;
+        polar(theta, wr, wi);
+        for (int i = 0; i < M; i++) {
+            t[((size_t)section * M + i) * 2] = pr;
+            t[((size_t)section * M + i) * 2 + 1] = pi;
+            double nr, ni;
+            cmul(pr, pi, wr, wi, nr, ni);
+            pr = nr;
+            pi = ni;
+        }
+    };
+    fill_powers(0, M_PI / (M * 2));
+    fill_powers(1, -M_PI * 2 / M);
+    fill_powers(2, -M_PI / (M * 2));
+    for (int i = 0; i < M; i++) {
+        const int src = i == 0 ? 0 : M - i;
+        t[((size_t)3 * M + i) * 2] = t[((size_t)1 * M + src) * 2];
+        t[((size_t)3 * M + i) * 2 + 1] = t[((size_t)1 * M + src) * 2 + 1];
+    }
+    return t;
+}
+
 // twiddle table of the workgroup NTT: forward rows of groups 1.., then inverse rows (ntt_wg.hpp)
 template <int LOGN>
 std::vector<double> build_tw_table_wg(const TwiddleSet& t) {
@@ -253,7 +297,10 @@ int check_batch(const tfhe_amd_ctx* ctx, size_t n_gates, bool ptrs_ok) {
 int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, uint32_t* out, size_t n_gates,
                      int extract, hipStream_t s) {
     const tfhe_amd_params& p = ctx->p;
-    if (ctx->fast)
+    if (ctx->replica)
+        HIP_TRY(launch_blind_rotate_replica(ctx->d_spec, ctx->d_tw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit,
+                                            extract, s));
+    else if (ctx->fast)
         HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)n_gates, p.n, p.K, p.L,
                                         extract, ctx->form, s));
     else if (ctx->wg)
@@ -402,6 +449,9 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     if (!bk && !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "both key pointers are null");
     int rc = tfhe_amd_params_supported(p);
     if (rc) return rc;
+    if ((flags & TFHE_AMD_CTX_REFERENCE_FFT) && !replica_has_kernel(p->N, p->K, p->L))
+        return fail(TFHE_AMD_ERR_UNSUPPORTED, "no reference-FFT kernel for this ring (the reference multiplies "
+                                              "exactly below degree 32; above 1024 the spectra exceed LDS)");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
@@ -413,8 +463,10 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     if (!ctx) return fail(TFHE_AMD_ERR_MEMORY, "host allocation failed");
     ctx->p = *p;
     ctx->device = device;
-    ctx->fast = fast_supported(p) && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
-    ctx->wg = !ctx->fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit) && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
+    ctx->replica = (flags & TFHE_AMD_CTX_REFERENCE_FFT) != 0;
+    const bool special = !ctx->replica && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
+    ctx->fast = special && fast_supported(p);
+    ctx->wg = special && !ctx->fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit);
     ctx->form = (flags & TFHE_AMD_CTX_LATENCY_FORM) ? 1 : (flags & TFHE_AMD_CTX_THROUGHPUT_FORM) ? 2 : 0;
     auto bail = [&](hipError_t e, const char* what) {
         tfhe_amd_ctx_destroy(ctx);
@@ -432,7 +484,18 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     DevBuf up_bk, up_ks;  // upload scratch for host-resident keys
     if (bk) {
         const uint32_t* src = bk;
-        if (ctx->fast) {
+        if (ctx->replica) {
+            const std::vector<double> tab = build_replica_tables(p->N);
+            CTX_TRY(hipMalloc(&ctx->d_tw, tab.size() * sizeof(double)));
+            CTX_TRY(hipMemcpy(ctx->d_tw, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+            CTX_TRY(hipMalloc(&ctx->d_spec, bk_words * sizeof(double)));  // N/2 complex doubles per polynomial
+            if (!on_device) {
+                CTX_TRY(up_bk.alloc(bk_words * sizeof(uint32_t)));
+                CTX_TRY(hipMemcpyAsync(up_bk.p, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                src = up_bk.as<uint32_t>();
+            }
+            CTX_TRY(launch_replica_key(src, ctx->d_tw, ctx->d_spec, bk_words / p->N, p->N, ctx->stream));
+        } else if (ctx->fast) {
             const TwiddleSet tw = make_twiddles(p->N);
             build_uniform(ctx->u, tw);
             const std::vector<double> blk = build_tw_block_512(tw);
@@ -564,7 +627,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
-    void* bufs[] = {ctx->d_tw, ctx->d_bk_ntt, ctx->d_bk_raw, ctx->d_ks, ctx->d_c, ctx->d_lv1, ctx->d_io};
+    void* bufs[] = {ctx->d_tw, ctx->d_bk_ntt, ctx->d_bk_raw, ctx->d_spec, ctx->d_ks, ctx->d_c, ctx->d_lv1, ctx->d_io};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

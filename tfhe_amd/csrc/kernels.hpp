@@ -25,6 +25,13 @@ hipError_t launch_bk_transform_512(const NttUniform& u, const d2* tw, const uint
 hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* bk_ntt, const uint32_t* c,
                                    const uint32_t* tv, uint32_t* out, int n_gates, int n, int K, int L, int extract,
                                    int form, hipStream_t stream);
+// blind rotation through a replay of the reference's FFT product (replica_kernels.hip); tables: [4][N/2]
+// complex (twist, omega, untwist, reversed omega powers); spec: [polys][N/2] complex key spectra
+bool replica_has_kernel(int N, int K, int L);
+hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, size_t n_polys, int N, hipStream_t stream);
+hipError_t launch_blind_rotate_replica(const d2* spec, const d2* tables, const uint32_t* c, const uint32_t* tv,
+                                       uint32_t* out, size_t n_gates, int n, int N, int K, int L, int bg, int extract,
+                                       hipStream_t stream);
 // evaluation-key generation (keygen_kernels.hip): raw keys in the flat layouts of tfhe_amd.h, device memory
 hipError_t launch_keygen_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, int n, int N, int K, int L,
                             int bg_bit, double alpha, uint64_t seed, hipStream_t stream);

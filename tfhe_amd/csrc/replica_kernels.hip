@@ -1,0 +1,226 @@
+// Blind rotation with the negacyclic products evaluated the way the REFERENCE evaluates them: its
+// double-precision complex FFT (reference src/types.hpp:152-197 and :237-292), replayed operation
+// by operation, rounding included.  The reference's product is the exact one or one unit lower,
+// depending on the rounding of that FFT; a context created with TFHE_AMD_CTX_REFERENCE_FFT therefore
+// returns ciphertexts that are bit-identical to those of the reference compiled without FMA
+// contraction (g++ -O2 on x86-64, the reference's CI build), where the default exact NTT path
+// returns the exact ones.  Verification mode: one workgroup per gate, no attempt at speed.
+//
+// What is replayed (M = N/2): fold N reals into M complex numbers (first half real parts, second half
+// imaginary parts); twist by powers of e^(i pi / N) built by repeated multiplication; an M-point
+// transform whose stage i multiplies the upper half of block j by omega^bitrev(2j), adds and
+// subtracts, followed by a bit-reversal permutation; pointwise product; the same transform with the
+// omega table reversed from index 1; scale by 1/M; untwist; truncating double -> torus conversion of
+// every part (reference src/types.hpp:28-33); the (K+1)L products of a column are summed mod 2^32
+// after each has been rounded on its own (reference src/types.hpp:433-445).  Complex products are
+// (ac - bd, ad + bc) in plain IEEE double operations; the library is built with -ffp-contract=off.
+// The power tables come from the host (capi.hip), where libm's cos and sin are the ones the
+// reference's std::polar calls.  The butterflies of a stage touch disjoint pairs, so running them in
+// place and in parallel gives the same values as the reference's array-per-stage loop; the final
+// permutation is folded into the indices of the next read.
+#include "kernels.hpp"
+
+namespace tfhe_amd {
+
+namespace {
+
+constexpr int kRepThreads = 256;
+
+__device__ __forceinline__ d2 c_mul(d2 x, d2 y) {
+    const double ac = x.x * y.x, bd = x.y * y.y, ad = x.x * y.y, bc = x.y * y.x;
+    d2 r;
+    r.x = ac - bd;
+    r.y = ad + bc;
+    return r;
+}
+
+__device__ __forceinline__ int bitrev(int v, int bits) { return (int)(__brev((unsigned)v) >> (32 - bits)); }
+
+// reference src/types.hpp:28-33; the conversion goes through 64 bits as on x86-64, where a value
+// that rounds up to exactly 2^32 wraps to 0
+__device__ __forceinline__ uint32_t torus_from_double_ref(double d) {
+    d = fmod(d, 1.0);
+    if (d < 0.0) d += 1.0;
+    d *= 4294967296.0;
+    return (uint32_t)(unsigned long long)d;
+}
+
+// `count` transforms of M points each, in place in LDS (buf: [count][M]), all stages.
+// omega: [M] table for this direction.  Output in bit-reversed positions.
+__device__ void fft_block(d2* buf, int count, int M, int bits, const d2* omega) {
+    const int half_total = count * (M >> 1);
+    for (int i = 0; i < bits; i++) {
+        const int span = 1 << (bits - i), half = span >> 1;
+        __syncthreads();
+        for (int t = threadIdx.x; t < half_total; t += kRepThreads) {
+            const int arr = t / (M >> 1), b = t - arr * (M >> 1);
+            const int j = b / half, k = b - j * half;
+            d2* a = buf + (size_t)arr * M + j * span + k;
+            const d2 even = a[0];
+            const d2 odd = c_mul(a[half], omega[bitrev(j << 1, bits)]);
+            d2 s, d;
+            s.x = even.x + odd.x; s.y = even.y + odd.y;
+            d.x = even.x - odd.x; d.y = even.y - odd.y;
+            a[0] = s;
+            a[half] = d;
+        }
+    }
+    __syncthreads();
+}
+
+struct RepShape {
+    int N, K1, L, R, bg, bits;  // bits = log2(N / 2)
+};
+
+}  // namespace
+
+// Tables: [4][M] complex = twist powers, forward omega powers, untwist powers, reversed omega powers.
+// Key spectra: for every key polynomial, fft(twist(fold(poly / 2^32))) in natural order, [M] complex.
+__global__ void __launch_bounds__(kRepThreads)
+replica_key_kernel(const uint32_t* __restrict__ bk, const d2* __restrict__ tables, d2* __restrict__ spec, int N,
+                   int bits) {
+    extern __shared__ d2 s_rep[];
+    const int M = N >> 1;
+    d2* s_omega = s_rep;      // [M]
+    d2* buf = s_rep + M;      // [M]
+    const size_t poly = blockIdx.x;
+    const uint32_t* b = bk + poly * N;
+    for (int i = threadIdx.x; i < M; i += kRepThreads) {
+        s_omega[i] = tables[M + i];
+        d2 v;
+        v.x = (double)b[i] / 4294967296.0;
+        v.y = (double)b[i + M] / 4294967296.0;
+        buf[i] = c_mul(v, tables[i]);
+    }
+    fft_block(buf, 1, M, bits, s_omega);
+    for (int i = threadIdx.x; i < M; i += kRepThreads) spec[poly * M + i] = buf[bitrev(i, bits)];
+}
+
+// One workgroup per gate.  Same interface as blind_rotate_generic_kernel.
+__global__ void __launch_bounds__(kRepThreads)
+blind_rotate_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ tables, const uint32_t* __restrict__ c,
+                            const uint32_t* __restrict__ tv, uint32_t* __restrict__ out, RepShape s, int n,
+                            int extract) {
+    extern __shared__ d2 s_rep[];
+    const int N = s.N, M = N >> 1, W = s.K1 * N, R = s.R, bits = s.bits;
+    d2* s_twist = s_rep;            // [M]
+    d2* s_omega = s_twist + M;      // [M]
+    d2* s_untwist = s_omega + M;    // [M]
+    d2* s_omega_r = s_untwist + M;  // [M]
+    d2* lhs = s_omega_r + M;        // [R][M] spectra of the digit polynomials (bit-reversed positions)
+    d2* prod = lhs + (size_t)R * M; // [R][M]
+    uint32_t* acc = reinterpret_cast<uint32_t*>(prod + (size_t)R * M);  // [K1][N]
+    uint32_t* diff = acc + W;                                           // [K1][N]
+    const size_t gate = blockIdx.x;
+    const uint32_t* cg = c + gate * (size_t)(n + 1);
+    const int sh = 32 - (bits + 2);  // 32 - log2(2N)
+
+    for (int i = threadIdx.x; i < 4 * M; i += kRepThreads) s_rep[i] = tables[i];
+    const int bbar = (int)(cg[0] >> sh);
+    for (int e = threadIdx.x; e < W; e += kRepThreads) {
+        const int q = e / N, j = e - q * N;
+        const int src = (j + bbar) & (2 * N - 1);
+        const uint32_t v = tv ? tv[q * N + (src & (N - 1))] : (q == 0 ? (1u << 29) : 0u);
+        acc[e] = (src & N) ? 0u - v : v;
+    }
+    __syncthreads();
+
+    uint32_t off = 1u << (32 - s.L * s.bg - 1);
+    for (int l = 0; l < s.L; l++) off += 1u << (32 - s.bg * (l + 1) + s.bg - 1);
+    const uint32_t mask = (1u << s.bg) - 1;
+    const int half_digit = 1 << (s.bg - 1);
+    const double scale = 1.0 / M;
+
+    for (int i = 0; i < n; i++) {
+        const int abar = (int)((cg[1 + i] + (1u << (sh - 1))) >> sh);
+        for (int e = threadIdx.x; e < W; e += kRepThreads) {
+            const int q = e / N, j = e - q * N;
+            const int src = (j - abar) & (2 * N - 1);
+            const uint32_t v = acc[q * N + (src & (N - 1))];
+            diff[e] = ((src & N) ? 0u - v : v) - acc[e];
+        }
+        __syncthreads();
+        // digit polynomial r = q*L + l, folded and twisted
+        for (int e = threadIdx.x; e < R * M; e += kRepThreads) {
+            const int r = e / M, m = e - r * M, q = r / s.L, l = r - q * s.L;
+            const uint32_t t0 = diff[q * N + m] + off, t1 = diff[q * N + m + M] + off;
+            d2 v;
+            v.x = (double)((int)((t0 >> (32 - s.bg * (l + 1))) & mask) - half_digit);
+            v.y = (double)((int)((t1 >> (32 - s.bg * (l + 1))) & mask) - half_digit);
+            lhs[e] = c_mul(v, s_twist[m]);
+        }
+        fft_block(lhs, R, M, bits, s_omega);
+        const d2* key = spec + (size_t)i * R * s.K1 * M;
+        for (int col = 0; col < s.K1; col++) {
+            for (int e = threadIdx.x; e < R * M; e += kRepThreads) {
+                const int r = e / M, m = e - r * M;
+                prod[e] = c_mul(lhs[r * M + bitrev(m, bits)], key[((size_t)r * s.K1 + col) * M + m]);
+            }
+            fft_block(prod, R, M, bits, s_omega_r);
+            // every product rounded to the torus on its own, then summed mod 2^32 and added to acc
+            for (int m = threadIdx.x; m < M; m += kRepThreads) {
+                uint32_t lo = 0, hi = 0;
+                for (int r = 0; r < R; r++) {
+                    d2 v = prod[r * M + bitrev(m, bits)];
+                    v.x *= scale;
+                    v.y *= scale;
+                    v = c_mul(v, s_untwist[m]);
+                    lo += torus_from_double_ref(v.x);
+                    hi += torus_from_double_ref(v.y);
+                }
+                acc[col * N + m] += lo;
+                acc[col * N + m + M] += hi;
+            }
+            __syncthreads();
+        }
+    }
+    if (extract) {
+        uint32_t* o = out + gate * (size_t)((s.K1 - 1) * N + 1);
+        for (int e = threadIdx.x; e < (s.K1 - 1) * N; e += kRepThreads) {
+            const int q = e / N, j = e - q * N;
+            const uint32_t v = acc[(1 + q) * N + j];
+            if (j == 0) o[1 + q * N] = v;
+            else        o[1 + q * N + (N - j)] = 0u - v;
+        }
+        if (threadIdx.x == 0) o[0] = acc[0];
+    } else {
+        for (int e = threadIdx.x; e < W; e += kRepThreads) out[gate * (size_t)W + e] = acc[e];
+    }
+}
+
+static size_t replica_lds_bytes(int N, int K1, int R) {
+    const size_t M = (size_t)N / 2;
+    return sizeof(d2) * (4 * M + 2 * (size_t)R * M) + sizeof(uint32_t) * (size_t)2 * K1 * N;
+}
+
+// the reference multiplies exactly below ring degree 32 (src/types.hpp:225-236): nothing to replay there
+bool replica_has_kernel(int N, int K, int L) {
+    if (N < 32 || N > 2048 || (N & (N - 1))) return false;
+    return replica_lds_bytes(N, K + 1, (K + 1) * L) <= 160 * 1024;
+}
+
+hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, size_t n_polys, int N, hipStream_t stream) {
+    if (n_polys == 0) return hipSuccess;
+    int bits = 0;
+    while ((1 << bits) < N / 2) bits++;
+    const size_t lds = sizeof(d2) * (size_t)N;  // 2 M
+    replica_key_kernel<<<(unsigned)n_polys, kRepThreads, lds, stream>>>(bk, tables, spec, N, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_replica(const d2* spec, const d2* tables, const uint32_t* c, const uint32_t* tv,
+                                       uint32_t* out, size_t n_gates, int n, int N, int K, int L, int bg, int extract,
+                                       hipStream_t stream) {
+    if (n_gates == 0) return hipSuccess;
+    if (!replica_has_kernel(N, K, L)) return hipErrorInvalidValue;
+    RepShape s{N, K + 1, L, (K + 1) * L, bg, 0};
+    while ((1 << s.bits) < N / 2) s.bits++;
+    const size_t lds = replica_lds_bytes(N, s.K1, s.R);
+    hipError_t e = hipFuncSetAttribute((const void*)blind_rotate_replica_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    blind_rotate_replica_kernel<<<(unsigned)n_gates, kRepThreads, lds, stream>>>(spec, tables, c, tv, out, s, n, extract);
+    return hipGetLastError();
+}
+
+}  // namespace tfhe_amd
