@@ -1,0 +1,48 @@
+"""Known-answer test at the DEFAULT parameters against the compiled reference, without needing the
+reference at test time: tests/golden/refnand512.npz (made by oracle/make_golden_nand512.py) holds 8
+input pairs and the ciphertexts HomNAND<>::nand of the real reference returned for them under an
+evaluation key regenerated here from the recorded seed (its checksum is recorded too).  With the
+reference's FFT product replayed, the oracle and the GPU must return exactly those ciphertexts;
+with the exact product, the same decrypted bits."""
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent / "oracle"))
+from make_golden_nand512 import key_checksum  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def case(golden):
+    g = golden("refnand512")
+    p = O.params_default()
+    s0, sr, bk, ks = O.keyset(p, seed=int(g["key_seed"][0]))
+    if not np.array_equal(key_checksum(bk, ks), g["key_checksum"]) or not np.array_equal(s0, g["s0"]):
+        pytest.skip("the oracle's seeded keygen does not regenerate the recorded key on this machine (libm differs)")
+    return p, g, bk, ks
+
+
+def test_oracle_replay_equals_recorded_reference_output(case):
+    p, g, bk, ks = case
+    for i in (0, 5):
+        assert np.array_equal(O.nand(g["a"][i], g["b"][i], bk, ks, p, 2), g["out"][i])
+    exact = O.Context(p, bk, ks).nand_batch(g["a"], g["b"])
+    want = 1 - (g["bits_a"] & g["bits_b"])
+    assert np.array_equal(O.decrypt_bits(exact, g["s0"], p), want)
+    assert np.array_equal(O.decrypt_bits(g["out"], g["s0"], p), want)
+
+
+@pytest.mark.gpu
+def test_gpu_replay_equals_recorded_reference_output(case):
+    import tfhe_amd
+
+    p, g, bk, ks = case
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks, reference_fft=True) as ctx:
+        assert np.array_equal(ctx.nand(g["a"], g["b"]), g["out"])
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks) as ctx:
+        exact = ctx.nand(g["a"], g["b"])
+    assert np.array_equal(exact, O.Context(p, bk, ks).nand_batch(g["a"], g["b"]))
+    assert np.array_equal(O.decrypt_bits(exact, g["s0"], p), 1 - (g["bits_a"] & g["bits_b"]))
