@@ -46,3 +46,22 @@ def test_gpu_replay_equals_recorded_reference_output(case):
         exact = ctx.nand(g["a"], g["b"])
     assert np.array_equal(exact, O.Context(p, bk, ks).nand_batch(g["a"], g["b"]))
     assert np.array_equal(O.decrypt_bits(exact, g["s0"], p), 1 - (g["bits_a"] & g["bits_b"]))
+
+
+@pytest.mark.gpu
+def test_wave_and_workgroup_replay_kernels_agree(case):
+    """The wave-per-gate replay kernel of the default set against the parameter-generic
+    one-workgroup-per-gate replay kernel, on encrypted and on arbitrary inputs, both blind-rotation
+    outputs (accumulator and extracted sample)."""
+    import tfhe_amd
+
+    p, g, bk, ks = case
+    rs = np.random.RandomState(8)
+    c = np.concatenate([np.stack([O.nand_combine(x, y, p) for x, y in zip(g["a"], g["b"])]),
+                        rs.randint(0, 2**32, size=(9, p.n + 1), dtype=np.uint64).astype(np.uint32)])
+    tv = rs.randint(0, 2**32, size=(p.K + 1, p.N), dtype=np.uint64).astype(np.uint32)
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, None, reference_fft=True) as fast, \
+            tfhe_amd.Context(tfhe_amd.params_default(), bk, None, reference_fft=True, generic_kernels=True) as slow:
+        assert np.array_equal(fast.blind_rotate(c), slow.blind_rotate(c))
+        assert np.array_equal(fast.blind_rotate(c, tv), slow.blind_rotate(c, tv))
+        assert np.array_equal(fast.gate_bootstrapping_tlwe_to_tlwe(c), slow.gate_bootstrapping_tlwe_to_tlwe(c))

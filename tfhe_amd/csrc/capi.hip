@@ -13,6 +13,7 @@
 #include "../../include/tfhe_amd.h"
 #include "field.hpp"
 #include "kernels.hpp"
+#include "fft256_wave.hpp"
 #include "ntt512_half.hpp"
 #include "ntt_wg.hpp"
 
@@ -66,6 +67,7 @@ struct tfhe_amd_ctx {
     bool fast = false;             // specialised NTT kernels (N = 512, K = 2, L = 2, 8-bit gadget)
     bool wg = false;               // workgroup-cooperative NTT kernels (N = 2048 set)
     bool replica = false;          // products through a replay of the reference's FFT (verification)
+    bool replica_generic = false;  // ... with the one-workgroup-per-gate kernel even at the default set
     d2* d_spec = nullptr;          // replica: key spectra
     int parts = 1, shift = 0;      // key split of the wg path
     NttUniform u{};
@@ -201,6 +203,27 @@ std::vector<double> build_replica_tables(int N) {
         t[((size_t)3 * M + i) * 2] = t[((size_t)1 * M + src) * 2];
         t[((size_t)3 * M + i) * 2 + 1] = t[((size_t)1 * M + src) * 2 + 1];
     }
+    if (M == 256) {
+        // block of the wave-per-gate kernel (fft256_wave.hpp): per-lane twiddle rows of both
+        // directions, then the untwist powers in the transform's output (position) order
+        t.resize((size_t)(4 * M + kFftFastPairs) * 2);
+        auto copy = [&](size_t dst_pair, size_t src_pair) {
+            t[dst_pair * 2] = t[src_pair * 2];
+            t[dst_pair * 2 + 1] = t[src_pair * 2 + 1];
+        };
+        const size_t base = (size_t)4 * M;
+        for (int dir = 0; dir < 2; dir++) {
+            const size_t tab = (size_t)(dir ? 3 : 1) * M;
+            for (int g = 1; g <= 4; g++)
+                for (int U = 0; U < (1 << (2 * (g - 1))); U++) {
+                    const size_t row = base + (dir ? kFftInvRows : kFftFwdRows) + 3 * (size_t)(fft_row_offset(g) + U);
+                    copy(row, tab + bit_reverse(2 * U, 8));
+                    copy(row + 1, tab + bit_reverse(4 * U, 8));
+                    copy(row + 2, tab + bit_reverse(4 * U + 2, 8));
+                }
+        }
+        for (int m = 0; m < M; m++) copy(base + kFftUntwistPos + m, (size_t)2 * M + bit_reverse(m, 8));
+    }
     return t;
 }
 
@@ -299,7 +322,7 @@ int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, u
     const tfhe_amd_params& p = ctx->p;
     if (ctx->replica)
         HIP_TRY(launch_blind_rotate_replica(ctx->d_spec, ctx->d_tw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit,
-                                            extract, s));
+                                            extract, ctx->replica_generic ? 1 : 0, s));
     else if (ctx->fast)
         HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)n_gates, p.n, p.K, p.L,
                                         extract, ctx->form, s));
@@ -464,6 +487,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     ctx->p = *p;
     ctx->device = device;
     ctx->replica = (flags & TFHE_AMD_CTX_REFERENCE_FFT) != 0;
+    ctx->replica_generic = ctx->replica && (flags & TFHE_AMD_CTX_GENERIC_KERNELS);
     const bool special = !ctx->replica && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
     ctx->fast = special && fast_supported(p);
     ctx->wg = special && !ctx->fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit);

@@ -1,0 +1,123 @@
+// One wave evaluates the 256-point complex transform of the reference's FFT product
+// (reference src/types.hpp:152-197) with exactly the reference's floating-point operations:
+// stage i multiplies the upper half of block j by omega_table[bitrev(2j)] as (ac - bd, ad + bc) and
+// forms even + odd, even - odd.  The butterflies of a stage touch disjoint pairs, so the order in
+// which lanes run them does not matter; only the operations inside one butterfly do.
+//
+// 4 complex points per lane, held as separate real and imaginary registers; the position maps and
+// the padded wave-private LDS transposes are those of ntt512_half.hpp (a 256-point, 8-stage
+// network of the same shape): layouts 1..4 cover stages (0,1), (2,3), (4,5), (6,7).  After the last
+// stage the element at position m is the output of natural index bitrev8(m) (the reference ends
+// with that permutation; here it is folded into what reads the result).
+//
+// Twiddle rows: group g = 1..4 starts at stage i0 = 2 (g - 1); a lane's block there is
+// U = its position >> (8 - i0); row U = [T[brev8(2U)], T[brev8(4U)], T[brev8(4U + 2)]] for the
+// direction's table T (the omega powers, or the omega powers reversed from index 1).
+#pragma once
+
+#include "ntt512_half.hpp"
+
+namespace tfhe_amd {
+
+struct Cx4 {
+    double re[4], im[4];
+};
+
+constexpr int kFftRows = 1 + 4 + 16 + 64;  // rows per direction
+__host__ __device__ constexpr int fft_row_offset(int g) { return g == 1 ? 0 : (g == 2 ? 1 : (g == 3 ? 5 : 21)); }
+// table block appended to the [4][256] base tables of the replica mode, in complex (d2) units:
+//   forward rows [85][3] | reversed-omega rows [85][3] | untwist powers permuted to position order [256]
+constexpr int kFftFwdRows = 0, kFftInvRows = kFftRows * 3, kFftUntwistPos = 2 * kFftRows * 3;
+constexpr int kFftFastPairs = 2 * kFftRows * 3 + 256;
+
+template <int G>
+__device__ __forceinline__ int fft_row(int lane) {
+    if (G == 1) return 0;
+    if (G == 2) return lane >> 4;
+    if (G == 3) return lane >> 2;
+    return lane;
+}
+
+// reference: odd *= w; lo = even + odd; hi = even - odd
+__device__ __forceinline__ void cx_butterfly(double& ar, double& ai, double& br, double& bi, d2 w) {
+    const double ac = br * w.x, bd = bi * w.y, ad = br * w.y, bc = bi * w.x;
+    const double orr = ac - bd, oi = ad + bc;
+    br = ar - orr;
+    bi = ai - oi;
+    ar = ar + orr;
+    ai = ai + oi;
+}
+
+// two stages on the 4 points of a lane: pairs (0,2), (1,3) with row[0], then (0,1) with row[1], (2,3) with row[2]
+__device__ __forceinline__ void cx_group(Cx4& x, const d2* row) {
+    const d2 w0 = row[0], w1 = row[1], w2 = row[2];
+    cx_butterfly(x.re[0], x.im[0], x.re[2], x.im[2], w0);
+    cx_butterfly(x.re[1], x.im[1], x.re[3], x.im[3], w0);
+    cx_butterfly(x.re[0], x.im[0], x.re[1], x.im[1], w1);
+    cx_butterfly(x.re[2], x.im[2], x.re[3], x.im[3], w2);
+}
+
+// tr: two planes of kHalfTrWords doubles
+template <int FROM, int TO>
+__device__ __forceinline__ void cx_transpose(Cx4& x, double* tr, int lane) {
+    constexpr int T = FROM < TO ? FROM : TO;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int a = half_pad<T>(half_pos<FROM>(lane, k));
+        tr[a] = x.re[k];
+        tr[kHalfTrWords + a] = x.im[k];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int a = half_pad<T>(half_pos<TO>(lane, k));
+        x.re[k] = tr[a];
+        x.im[k] = tr[kHalfTrWords + a];
+    }
+    wave_lds_fence();
+}
+
+// In: layout 1 (position 64 k + lane).  Out: layout 4 (position 4 lane + k), i.e. natural index
+// bitrev8(4 lane + k).  rows: this direction's [85][3] table in LDS.
+__device__ __forceinline__ void fft256_wave(Cx4& x, const d2* rows, double* tr, int lane) {
+    cx_group(x, rows + 3 * (fft_row_offset(1) + fft_row<1>(lane)));
+    cx_transpose<1, 2>(x, tr, lane);
+    cx_group(x, rows + 3 * (fft_row_offset(2) + fft_row<2>(lane)));
+    cx_transpose<2, 3>(x, tr, lane);
+    cx_group(x, rows + 3 * (fft_row_offset(3) + fft_row<3>(lane)));
+    cx_transpose<3, 4>(x, tr, lane);
+    cx_group(x, rows + 3 * (fft_row_offset(4) + fft_row<4>(lane)));
+}
+
+__device__ __forceinline__ int brev8(int v) { return (int)(__brev((unsigned)v) >> 24); }
+
+// From the transform's output order (layout 4) to natural order in layout 1: lane (l, k) ends up
+// with natural index 64 k + l, which sits at position bitrev8(64 k + l).
+__device__ __forceinline__ void cx_to_natural(Cx4& x, double* tr, int lane) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = 4 * lane + k, a = p + (p >> 3);
+        tr[a] = x.re[k];
+        tr[kHalfTrWords + a] = x.im[k];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = brev8(64 * k + lane), a = p + (p >> 3);
+        x.re[k] = tr[a];
+        x.im[k] = tr[kHalfTrWords + a];
+    }
+    wave_lds_fence();
+}
+
+// reference src/types.hpp:28-33 for a finite d: fmod(d, 1), plus 1 if negative, times 2^32,
+// truncated through 64 bits (a value that rounds up to exactly 2^32 wraps to 0).  d - floor(d) is
+// the same real number as fmod(d, 1) (+ 1 for negative d) rounded once, like the reference's sum;
+// for d >= 0 and for negative integers both are exact.
+__device__ __forceinline__ uint32_t torus_from_double_fast(double d) {
+    const double f = d - __builtin_floor(d);
+    const double t = f * 4294967296.0;
+    return t >= 4294967296.0 ? 0u : (uint32_t)t;
+}
+
+}  // namespace tfhe_amd

@@ -29,9 +29,11 @@ hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* 
 // complex (twist, omega, untwist, reversed omega powers); spec: [polys][N/2] complex key spectra
 bool replica_has_kernel(int N, int K, int L);
 hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, size_t n_polys, int N, hipStream_t stream);
+// generic != 0: the one-workgroup-per-gate kernel even where the wave-per-gate one exists (cross-checking)
+bool replica_has_fast_kernel(int N, int K, int L, int bg);
 hipError_t launch_blind_rotate_replica(const d2* spec, const d2* tables, const uint32_t* c, const uint32_t* tv,
                                        uint32_t* out, size_t n_gates, int n, int N, int K, int L, int bg, int extract,
-                                       hipStream_t stream);
+                                       int generic, hipStream_t stream);
 // evaluation-key generation (keygen_kernels.hip): raw keys in the flat layouts of tfhe_amd.h, device memory
 hipError_t launch_keygen_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, int n, int N, int K, int L,
                             int bg_bit, double alpha, uint64_t seed, hipStream_t stream);

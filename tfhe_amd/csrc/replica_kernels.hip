@@ -18,6 +18,7 @@
 // reference's std::polar calls.  The butterflies of a stage touch disjoint pairs, so running them in
 // place and in parallel gives the same values as the reference's array-per-stage loop; the final
 // permutation is folded into the indices of the next read.
+#include "fft256_wave.hpp"
 #include "kernels.hpp"
 
 namespace tfhe_amd {
@@ -188,6 +189,171 @@ blind_rotate_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The default parameter set (N = 512, K = 2, L = 2) at speed: one WAVE per gate, the reference's
+// 256-point transforms evaluated in registers (fft256_wave.hpp), same structure as
+// blind_rotate_512_kernel.  Per step and digit polynomial: fold and twist, forward transform,
+// permutation to natural order, then per column: pointwise product with the key spectrum, the
+// second transform, scale, untwist, truncating conversion of both parts, wrap-around sum.  The
+// reference rounds every product on its own, so there are (K+1) L (K+1) = 18 second transforms per
+// step where the exact path needs K + 1 = 3 inverse NTTs.
+// tables: the [4][256] base tables followed by the block described in fft256_wave.hpp.
+// ------------------------------------------------------------------------------------------
+template <int K, int L>
+__global__ void __launch_bounds__(256, 2)
+blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ tables,
+                                const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv,
+                                uint32_t* __restrict__ out, int n_gates, int n, int extract) {
+    constexpr int K1 = K + 1, R = K1 * L, BG = 8, M = 256;
+    __shared__ d2 s_rows[2 * kFftRows * 3];
+    __shared__ d2 s_twist[M];
+    __shared__ d2 s_untwist[M];  // position order: entry m belongs to natural index bitrev8(m)
+    __shared__ double s_tr[4][2 * kHalfTrWords];
+    __shared__ uint32_t s_acc[4][K1][kN];
+
+    for (int i = threadIdx.x; i < 2 * kFftRows * 3; i += 256) s_rows[i] = tables[4 * M + i];
+    for (int i = threadIdx.x; i < M; i += 256) {
+        s_twist[i] = tables[i];
+        s_untwist[i] = tables[4 * M + kFftUntwistPos + i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gate = blockIdx.x * 4 + wave;
+    if (gate >= n_gates) return;  // waves are independent from here on
+    double* tr = s_tr[wave];
+    uint32_t(*acc)[kN] = s_acc[wave];
+    const uint32_t* cg = c + (size_t)gate * (n + 1);
+    const d2* rows_fwd = s_rows + kFftFwdRows;
+    const d2* rows_inv = s_rows + kFftInvRows;
+    {
+        const int bbar = (int)(cg[0] >> 22);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = 64 * k + lane;
+            const int s = (j + bbar) & (2 * kN - 1);
+#pragma unroll
+            for (int q = 0; q < K1; q++) {
+                const uint32_t v = tv ? tv[q * kN + (s & (kN - 1))] : (q == 0 ? (1u << 29) : 0u);
+                acc[q][j] = (s & kN) ? 0u - v : v;
+            }
+        }
+    }
+    wave_lds_fence();
+
+    uint32_t offset = 1u << (32 - L * BG - 1), flip = 0u;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        offset += 1u << (32 - BG * (l + 1) + BG - 1);
+        flip |= 1u << (32 - BG * (l + 1) + BG - 1);
+    }
+    d2 twist[4], untwist[4];
+    int nat[4];  // natural index of position 4 lane + k
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        twist[k] = s_twist[64 * k + lane];
+        untwist[k] = s_untwist[4 * lane + k];
+        nat[k] = brev8(4 * lane + k);
+    }
+    const double scale = 1.0 / M;
+
+    uint32_t cvals = 0;
+    for (int i = 0; i < n; i++) {
+        if ((i & 63) == 0) cvals = (i + lane < n) ? cg[1 + i + lane] : 0u;
+        const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cvals, i & 63);
+        const int abar = (int)((ci + (1u << 21)) >> 22);
+
+        uint32_t lo[K1][4], hi[K1][4];
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) lo[col][k] = hi[col][k] = 0u;
+
+        const d2* key_row = spec + (size_t)i * (R * K1 * M);
+#pragma unroll 1
+        for (int q = 0; q < K1; q++) {
+            uint32_t t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int sidx = (64 * k + lane - abar) & (2 * kN - 1);
+                const uint32_t neg = 0u - (uint32_t)((sidx >> 9) & 1);
+                const uint32_t v = acc[q][sidx & (kN - 1)];
+                t[k] = ((((v ^ neg) - neg) - acc[q][64 * k + lane]) + offset) ^ flip;
+            }
+#pragma unroll 1
+            for (int level = 0; level < L; level++) {
+                const d2* key = key_row + (size_t)(q * L + level) * K1 * M;
+                d2 y[K1][4];
+#pragma unroll
+                for (int col = 0; col < K1; col++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) y[col][k] = key[col * M + 64 * k + lane];
+                // fold (real part: coefficient m, imaginary part: coefficient m + 256) and twist
+                Cx4 x;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double dr = (double)(((int32_t)(t[k] << (BG * level))) >> (32 - BG));
+                    const double di = (double)(((int32_t)(t[k + 4] << (BG * level))) >> (32 - BG));
+                    const double ac = dr * twist[k].x, bd = di * twist[k].y, ad = dr * twist[k].y, bc = di * twist[k].x;
+                    x.re[k] = ac - bd;
+                    x.im[k] = ad + bc;
+                }
+                fft256_wave(x, rows_fwd, tr, lane);
+                cx_to_natural(x, tr, lane);
+#pragma unroll
+                for (int col = 0; col < K1; col++) {
+                    Cx4 pr;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const double ac = x.re[k] * y[col][k].x, bd = x.im[k] * y[col][k].y;
+                        const double ad = x.re[k] * y[col][k].y, bc = x.im[k] * y[col][k].x;
+                        pr.re[k] = ac - bd;
+                        pr.im[k] = ad + bc;
+                    }
+                    fft256_wave(pr, rows_inv, tr, lane);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const double sr = pr.re[k] * scale, si = pr.im[k] * scale;
+                        const double ac = sr * untwist[k].x, bd = si * untwist[k].y;
+                        const double ad = sr * untwist[k].y, bc = si * untwist[k].x;
+                        lo[col][k] += torus_from_double_fast(ac - bd);
+                        hi[col][k] += torus_from_double_fast(ad + bc);
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                acc[col][nat[k]] += lo[col][k];
+                acc[col][nat[k] + M] += hi[col][k];
+            }
+        wave_lds_fence();
+    }
+
+    if (!extract) {
+        uint32_t* o = out + (size_t)gate * (K1 * kN);
+#pragma unroll
+        for (int q = 0; q < K1; q++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) o[q * kN + 64 * k + lane] = acc[q][64 * k + lane];
+        return;
+    }
+    uint32_t* o = out + (size_t)gate * (K * kN + 1);
+    if (lane == 0) o[0] = acc[0][0];
+#pragma unroll
+    for (int q = 0; q < K; q++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = 64 * k + lane;
+            const uint32_t v = acc[1 + q][j];
+            if (j == 0) o[1 + q * kN] = v;
+            else        o[1 + q * kN + (kN - j)] = 0u - v;
+        }
+}
+
 static size_t replica_lds_bytes(int N, int K1, int R) {
     const size_t M = (size_t)N / 2;
     return sizeof(d2) * (4 * M + 2 * (size_t)R * M) + sizeof(uint32_t) * (size_t)2 * K1 * N;
@@ -208,11 +374,18 @@ hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, si
     return hipGetLastError();
 }
 
+bool replica_has_fast_kernel(int N, int K, int L, int bg) { return N == 512 && K == 2 && L == 2 && bg == 8; }
+
 hipError_t launch_blind_rotate_replica(const d2* spec, const d2* tables, const uint32_t* c, const uint32_t* tv,
                                        uint32_t* out, size_t n_gates, int n, int N, int K, int L, int bg, int extract,
-                                       hipStream_t stream) {
+                                       int generic, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
     if (!replica_has_kernel(N, K, L)) return hipErrorInvalidValue;
+    if (!generic && replica_has_fast_kernel(N, K, L, bg)) {
+        blind_rotate_512_replica_kernel<2, 2><<<(unsigned)((n_gates + 3) / 4), 256, 0, stream>>>(
+            spec, tables, c, tv, out, (int)n_gates, n, extract);
+        return hipGetLastError();
+    }
     RepShape s{N, K + 1, L, (K + 1) * L, bg, 0};
     while ((1 << s.bits) < N / 2) s.bits++;
     const size_t lds = replica_lds_bytes(N, s.K1, s.R);

@@ -13,7 +13,7 @@ rs = np.random.RandomState(0)
 bk = rs.randint(0, 2**32, size=p.bk_shape(), dtype=np.uint64).astype(np.uint32)
 ks = rs.randint(0, 2**32, size=p.ks_shape(), dtype=np.uint64).astype(np.uint32)
 ctx = tfhe_amd.Context(p, bk, ks, reference_fft=True)
-for G in (1, 256, 1024):
+for G in (1, 1024, 2048, 8192):
     a = torch.randint(-2**31, 2**31 - 1, (G, p.n1), dtype=torch.int32, device="cuda")
     b = torch.randint(-2**31, 2**31 - 1, (G, p.n1), dtype=torch.int32, device="cuda")
     out = torch.empty_like(a)
