@@ -130,6 +130,11 @@ def main():
         t_bcast = time.time() - t0
     bk, ks = bk.to(dev), ks.to(dev)
     ctx = tfhe_amd.Context(p, bk, ks, device=dev_index, keys_on_device=True)
+    # verification mode (products through a replay of the reference's FFT: output bit-identical to the
+    # compiled reference), timed beside the default path on one GPU
+    ctx_ref = None
+    if world == 1 and not args.no_extras:
+        ctx_ref = tfhe_amd.Context(p, bk, ks, device=dev_index, keys_on_device=True, reference_fft=True)
     del bk, ks
 
     gen = torch.Generator(device=dev)
@@ -225,6 +230,16 @@ def main():
             del a8, b8, out8
             line["other_batches"] = extra
             line["single_gate_latency_ms"] = extra["batch_1"]["ms"]
+            ctx_ref.nand_device(a, b, out); ctx_ref.synchronize()
+            t0 = time.perf_counter()
+            ctx_ref.nand_device(a, b, out)
+            ctx_ref.synchronize()
+            dt = time.perf_counter() - t0
+            ctx_ref.close()
+            line["reference_bit_identical_mode"] = {
+                "gates_per_s": G / dt, "ms": dt * 1e3, "gates": G,
+                "note": "TFHE_AMD_CTX_REFERENCE_FFT: ciphertexts bit-identical to the reference built with g++ -O2 "
+                        "(tests/test_reference_golden_nand512.py); the headline value is the exact-product path"}
         if world == 1:
             if not args.no_cpu_baseline:
                 threads = min(16, os.cpu_count() or 1)

@@ -48,13 +48,27 @@ __device__ __forceinline__ void cx_butterfly(double& ar, double& ai, double& br,
     ai = ai + oi;
 }
 
+// Two butterflies at once, written phase by phase (all eight products, then the four sums of
+// products, then the eight outputs) and fenced with scheduling barriers so that dependent FP64
+// instructions end up four or eight apart (see the phase-ordered forms in ntt512.hpp).  The
+// operations of each butterfly are the ones cx_butterfly performs, in the same order.
+__device__ __forceinline__ void cx_butterfly2(double& a0r, double& a0i, double& b0r, double& b0i, d2 w0, double& a1r,
+                                              double& a1i, double& b1r, double& b1i, d2 w1) {
+    const double ac0 = b0r * w0.x, bd0 = b0i * w0.y, ad0 = b0r * w0.y, bc0 = b0i * w0.x;
+    const double ac1 = b1r * w1.x, bd1 = b1i * w1.y, ad1 = b1r * w1.y, bc1 = b1i * w1.x;
+    pin();
+    const double or0 = ac0 - bd0, oi0 = ad0 + bc0, or1 = ac1 - bd1, oi1 = ad1 + bc1;
+    pin();
+    b0r = a0r - or0; b0i = a0i - oi0; b1r = a1r - or1; b1i = a1i - oi1;
+    a0r = a0r + or0; a0i = a0i + oi0; a1r = a1r + or1; a1i = a1i + oi1;
+    pin();
+}
+
 // two stages on the 4 points of a lane: pairs (0,2), (1,3) with row[0], then (0,1) with row[1], (2,3) with row[2]
 __device__ __forceinline__ void cx_group(Cx4& x, const d2* row) {
     const d2 w0 = row[0], w1 = row[1], w2 = row[2];
-    cx_butterfly(x.re[0], x.im[0], x.re[2], x.im[2], w0);
-    cx_butterfly(x.re[1], x.im[1], x.re[3], x.im[3], w0);
-    cx_butterfly(x.re[0], x.im[0], x.re[1], x.im[1], w1);
-    cx_butterfly(x.re[2], x.im[2], x.re[3], x.im[3], w2);
+    cx_butterfly2(x.re[0], x.im[0], x.re[2], x.im[2], w0, x.re[1], x.im[1], x.re[3], x.im[3], w0);
+    cx_butterfly2(x.re[0], x.im[0], x.re[1], x.im[1], w1, x.re[2], x.im[2], x.re[3], x.im[3], w2);
 }
 
 // tr: two planes of kHalfTrWords doubles
