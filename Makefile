@@ -4,7 +4,7 @@ ARCH ?= gfx950
 # -ffp-contract=off: the NTT's exactness argument needs every multiply and FMA exactly as written
 HIPFLAGS ?= -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall
 SRC := tfhe_amd/csrc/kernels.hip tfhe_amd/csrc/generic_kernels.hip tfhe_amd/csrc/wg_kernels.hip tfhe_amd/csrc/keygen_kernels.hip tfhe_amd/csrc/replica_kernels.hip tfhe_amd/csrc/capi.hip
-HDR := tfhe_amd/csrc/kernels.hpp tfhe_amd/csrc/ntt512.hpp tfhe_amd/csrc/ntt512_half.hpp tfhe_amd/csrc/ntt_wg.hpp tfhe_amd/csrc/field.hpp include/tfhe_amd.h
+HDR := tfhe_amd/csrc/kernels.hpp tfhe_amd/csrc/ntt512.hpp tfhe_amd/csrc/ntt512_half.hpp tfhe_amd/csrc/fft256_wave.hpp tfhe_amd/csrc/ntt_wg.hpp tfhe_amd/csrc/field.hpp include/tfhe_amd.h
 
 all: tfhe_amd/libtfhe_amd.so oracle tests/cpp/dropin_test
 

@@ -30,6 +30,16 @@ inline int& device() {  // GPU used by the header-level calls; change before the
     return dev;
 }
 
+// Context flags (TFHE_AMD_CTX_*) for the contexts the headers create.  Setting
+// TFHE_AMD_CTX_REFERENCE_FFT makes nand() and the blind rotations return the ciphertexts of the
+// reference built with g++ -O2 bit for bit (its FFT product replayed) instead of the exact ones;
+// the ring must support it (degree 32 .. 1024).  Change before the first evaluation with a key, or
+// call cache().clear().
+inline unsigned& context_flags() {
+    static unsigned flags = TFHE_AMD_CTX_DEFAULT;
+    return flags;
+}
+
 // ---- flatten / unflatten -------------------------------------------------------------------
 template <int N>
 void put(std::vector<uint32_t>& out, const Vector<TorusValue, N>& v) {
@@ -88,6 +98,7 @@ class ContextCache {
         const void* ks_id;
         uint64_t print;
         tfhe_amd_params params;
+        unsigned flags;
         tfhe_amd_ctx* ctx;
     };
     std::list<Entry> entries_;
@@ -111,7 +122,7 @@ public:
     tfhe_amd_ctx* get(const tfhe_amd_params& params, const void* bk_id, const void* ks_id, uint64_t print,
                       MakeBk make_bk, MakeKs make_ks) {
         for (auto it = entries_.begin(); it != entries_.end(); ++it)
-            if (it->bk_id == bk_id && it->ks_id == ks_id && same(it->params, params)) {
+            if (it->bk_id == bk_id && it->ks_id == ks_id && same(it->params, params) && it->flags == context_flags()) {
                 if (it->print == print) {
                     entries_.splice(entries_.begin(), entries_, it);
                     return entries_.front().ctx;
@@ -123,9 +134,9 @@ public:
         const std::vector<uint32_t> bk = make_bk(), ks = make_ks();
         tfhe_amd_ctx* ctx = nullptr;
         check(tfhe_amd_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(),
-                                  device(), TFHE_AMD_CTX_DEFAULT, &ctx),
+                                  device(), context_flags(), &ctx),
               "tfhe_amd_ctx_create");
-        entries_.push_front(Entry{bk_id, ks_id, print, params, ctx});
+        entries_.push_front(Entry{bk_id, ks_id, print, params, context_flags(), ctx});
         if (entries_.size() > kMaxEntries) {
             tfhe_amd_ctx_destroy(entries_.back().ctx);
             entries_.pop_back();

@@ -249,6 +249,20 @@ static void test_other_gates() {  // not in the reference: truth tables of the o
     }
 }
 
+static void test_reference_fft_mode() {  // same gates, products through the reference's FFT replayed
+    HomNAND<> h(21);
+    auto sk = h.generate_secret_key();
+    auto ek = h.make_evaluate_key_gpu(sk, 3);
+    auto a = h.encrypt(true, sk), b = h.encrypt(false, sk);
+    auto exact = h.nand(a, b, ek);
+    gpu::context_flags() = TFHE_AMD_CTX_REFERENCE_FFT;
+    auto replay = h.nand(a, b, ek);
+    gpu::context_flags() = TFHE_AMD_CTX_DEFAULT;
+    CHECK(h.decrypt(exact, sk) && h.decrypt(replay, sk));
+    CHECK(!(exact == replay));            // the reference's product is one unit low here and there
+    CHECK(h.nand(a, b, ek) == exact);     // back on the exact path
+}
+
 static void test_gpu_keygen() {  // make_evaluate_key_gpu: not in the reference
     HomNAND<> h(5);
     auto sk = h.generate_secret_key();
@@ -286,6 +300,7 @@ static void run_gpu() {
     test_hom_nand();
     test_other_gates();
     test_gpu_keygen();
+    test_reference_fft_mode();
     test_hom_nand_other_ring();
     std::puts("gpu group ok");
 }
