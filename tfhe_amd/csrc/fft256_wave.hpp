@@ -71,6 +71,20 @@ __device__ __forceinline__ void cx_group(Cx4& x, const d2* row) {
     cx_butterfly2(x.re[0], x.im[0], x.re[1], x.im[1], w1, x.re[2], x.im[2], x.re[3], x.im[3], w2);
 }
 
+// The first group (stages 0 and 1): block 0 of every table entry is T[0] = (1, 0) exactly, and
+// multiplying by it returns the operand unchanged (b.re * 1 - b.im * 0, b.re * 0 + b.im * 1; only
+// the sign of a zero can differ, which no later operation or the final conversion can see), so
+// three of the four butterflies are additions only.  w23 = T[bitrev8(2)] = T[64], wave-uniform.
+__device__ __forceinline__ void cx_group_first(Cx4& x, d2 w23) {
+    double s, d;
+#define TFHE_AMD_ADDSUB(a, b) s = a + b; d = a - b; a = s; b = d;
+    TFHE_AMD_ADDSUB(x.re[0], x.re[2]) TFHE_AMD_ADDSUB(x.im[0], x.im[2])
+    TFHE_AMD_ADDSUB(x.re[1], x.re[3]) TFHE_AMD_ADDSUB(x.im[1], x.im[3])
+    TFHE_AMD_ADDSUB(x.re[0], x.re[1]) TFHE_AMD_ADDSUB(x.im[0], x.im[1])
+#undef TFHE_AMD_ADDSUB
+    cx_butterfly(x.re[2], x.im[2], x.re[3], x.im[3], w23);
+}
+
 // tr: two planes of kHalfTrWords doubles
 template <int FROM, int TO>
 __device__ __forceinline__ void cx_transpose(Cx4& x, double* tr, int lane) {
@@ -92,9 +106,9 @@ __device__ __forceinline__ void cx_transpose(Cx4& x, double* tr, int lane) {
 }
 
 // In: layout 1 (position 64 k + lane).  Out: layout 4 (position 4 lane + k), i.e. natural index
-// bitrev8(4 lane + k).  rows: this direction's [85][3] table in LDS.
-__device__ __forceinline__ void fft256_wave(Cx4& x, const d2* rows, double* tr, int lane) {
-    cx_group(x, rows + 3 * (fft_row_offset(1) + fft_row<1>(lane)));
+// bitrev8(4 lane + k).  rows: this direction's [85][3] table in LDS; w23 = its row 0, entry 2.
+__device__ __forceinline__ void fft256_wave(Cx4& x, const d2* rows, d2 w23, double* tr, int lane) {
+    cx_group_first(x, w23);
     cx_transpose<1, 2>(x, tr, lane);
     cx_group(x, rows + 3 * (fft_row_offset(2) + fft_row<2>(lane)));
     cx_transpose<2, 3>(x, tr, lane);

@@ -255,7 +255,15 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
         untwist[k] = s_untwist[4 * lane + k];
         nat[k] = brev8(4 * lane + k);
     }
+    // The reference scales by 1/M = 2^-8 and then multiplies by the untwist power; a power of two
+    // commutes exactly with every later rounding, so it is folded into the power.
     const double scale = 1.0 / M;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        untwist[k].x *= scale;
+        untwist[k].y *= scale;
+    }
+    const d2 w23_fwd = rows_fwd[2], w23_inv = rows_inv[2];
 
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
@@ -298,7 +306,7 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                     x.re[k] = ac - bd;
                     x.im[k] = ad + bc;
                 }
-                fft256_wave(x, rows_fwd, tr, lane);
+                fft256_wave(x, rows_fwd, w23_fwd, tr, lane);
                 cx_to_natural(x, tr, lane);
 #pragma unroll
                 for (int col = 0; col < K1; col++) {
@@ -310,12 +318,11 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                         pr.re[k] = ac - bd;
                         pr.im[k] = ad + bc;
                     }
-                    fft256_wave(pr, rows_inv, tr, lane);
+                    fft256_wave(pr, rows_inv, w23_inv, tr, lane);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const double sr = pr.re[k] * scale, si = pr.im[k] * scale;
-                        const double ac = sr * untwist[k].x, bd = si * untwist[k].y;
-                        const double ad = sr * untwist[k].y, bc = si * untwist[k].x;
+                        const double ac = pr.re[k] * untwist[k].x, bd = pr.im[k] * untwist[k].y;
+                        const double ad = pr.re[k] * untwist[k].y, bc = pr.im[k] * untwist[k].x;
                         lo[col][k] += torus_from_double_fast(ac - bd);
                         hi[col][k] += torus_from_double_fast(ad + bc);
                     }
