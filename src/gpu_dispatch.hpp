@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
 #include <list>
 #include <stdexcept>
 #include <string>
@@ -34,9 +35,14 @@ inline int& device() {  // GPU used by the header-level calls; change before the
 // TFHE_AMD_CTX_REFERENCE_FFT makes nand() and the blind rotations return the ciphertexts of the
 // reference built with g++ -O2 bit for bit (its FFT product replayed) instead of the exact ones;
 // the ring must support it (degree 32 .. 1024).  Change before the first evaluation with a key, or
-// call cache().clear().
+// call cache().clear().  Unmodified programs can be switched from outside with the environment
+// variable TFHE_AMD_CONTEXT_FLAGS=16.
 inline unsigned& context_flags() {
-    static unsigned flags = TFHE_AMD_CTX_DEFAULT;
+    // initial value: the environment variable TFHE_AMD_CONTEXT_FLAGS (a number), else the default
+    static unsigned flags = [] {
+        const char* e = std::getenv("TFHE_AMD_CONTEXT_FLAGS");
+        return e ? (unsigned)std::strtoul(e, nullptr, 0) : (unsigned)TFHE_AMD_CTX_DEFAULT;
+    }();
     return flags;
 }
 

@@ -11,8 +11,11 @@ DROPIN = ROOT / "tests" / "cpp" / "dropin_test"
 REF_DRIVER = ROOT / "oracle" / "_ref" / "ref_tests_dropin"
 
 
-def _run(cmd, timeout):
-    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=timeout)
+def _run(cmd, timeout, env=None):
+    import os
+
+    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=timeout,
+                       env=None if env is None else {**os.environ, **env})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
@@ -37,3 +40,13 @@ def test_reference_driver_on_dropin_headers(name):
     if not REF_DRIVER.exists():
         pytest.skip("oracle/_ref/ref_tests_dropin not built (needs /root/reference at build time)")
     assert f"test_{name} passed" in _run([REF_DRIVER, name], 900)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["CMUX", "Bootstrapping", "HomNAND"])
+def test_reference_driver_in_reference_fft_mode(name):
+    """The same unmodified driver with the headers' contexts switched (from outside, through the
+    environment) to the replayed-FFT products, i.e. to the reference's own ciphertexts."""
+    if not REF_DRIVER.exists():
+        pytest.skip("oracle/_ref/ref_tests_dropin not built (needs /root/reference at build time)")
+    assert f"test_{name} passed" in _run([REF_DRIVER, name], 900, env={"TFHE_AMD_CONTEXT_FLAGS": "16"})
