@@ -106,11 +106,12 @@ __device__ __forceinline__ void cx_transpose(Cx4& x, double* tr, int lane) {
 }
 
 // In: layout 1 (position 64 k + lane).  Out: layout 4 (position 4 lane + k), i.e. natural index
-// bitrev8(4 lane + k).  rows: this direction's [85][3] table in LDS; w23 = its row 0, entry 2.
-__device__ __forceinline__ void fft256_wave(Cx4& x, const d2* rows, d2 w23, double* tr, int lane) {
+// bitrev8(4 lane + k).  rows: this direction's [85][3] table in LDS; w23 = its row 0, entry 2;
+// row2 = the lane's row of group 2 (four distinct rows per wave), kept in registers by the caller.
+__device__ __forceinline__ void fft256_wave(Cx4& x, const d2* rows, d2 w23, const d2 (&row2)[3], double* tr, int lane) {
     cx_group_first(x, w23);
     cx_transpose<1, 2>(x, tr, lane);
-    cx_group(x, rows + 3 * (fft_row_offset(2) + fft_row<2>(lane)));
+    cx_group(x, row2);
     cx_transpose<2, 3>(x, tr, lane);
     cx_group(x, rows + 3 * (fft_row_offset(3) + fft_row<3>(lane)));
     cx_transpose<3, 4>(x, tr, lane);

@@ -264,6 +264,12 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
         untwist[k].y *= scale;
     }
     const d2 w23_fwd = rows_fwd[2], w23_inv = rows_inv[2];
+    d2 row2_fwd[3], row2_inv[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        row2_fwd[e] = rows_fwd[3 * (fft_row_offset(2) + fft_row<2>(lane)) + e];
+        row2_inv[e] = rows_inv[3 * (fft_row_offset(2) + fft_row<2>(lane)) + e];
+    }
 
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
@@ -306,7 +312,7 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                     x.re[k] = ac - bd;
                     x.im[k] = ad + bc;
                 }
-                fft256_wave(x, rows_fwd, w23_fwd, tr, lane);
+                fft256_wave(x, rows_fwd, w23_fwd, row2_fwd, tr, lane);
                 cx_to_natural(x, tr, lane);
 #pragma unroll
                 for (int col = 0; col < K1; col++) {
@@ -318,7 +324,7 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                         pr.re[k] = ac - bd;
                         pr.im[k] = ad + bc;
                     }
-                    fft256_wave(pr, rows_inv, w23_inv, tr, lane);
+                    fft256_wave(pr, rows_inv, w23_inv, row2_inv, tr, lane);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const double ac = pr.re[k] * untwist[k].x, bd = pr.im[k] * untwist[k].y;
