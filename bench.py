@@ -230,6 +230,15 @@ def main():
             del a8, b8, out8
             line["other_batches"] = extra
             line["single_gate_latency_ms"] = extra["batch_1"]["ms"]
+            # host-pointer entry point: PCIe transfers of inputs and outputs included (pageable memory)
+            ha, hb = a.cpu().numpy().view(np.uint32), b.cpu().numpy().view(np.uint32)
+            ctx.nand(ha[:64], hb[:64])
+            t0 = time.perf_counter()
+            ctx.nand(ha, hb)
+            dt = time.perf_counter() - t0
+            line["pcie_inclusive"] = {"gates_per_s": G / dt, "ms": dt * 1e3, "gates": G,
+                                      "note": "tfhe_amd_nand_batch on host arrays: H2D of both operands, kernels, D2H"}
+            del ha, hb
             ctx_ref.nand_device(a, b, out); ctx_ref.synchronize()
             t0 = time.perf_counter()
             ctx_ref.nand_device(a, b, out)
