@@ -254,3 +254,52 @@ def test_mux_adder_32_bits_on_device(keys, ctx, octx):
     total = sum(int(v) << i for i, v in enumerate(O.decrypt_bits(got[sums], s0, p)))
     total += int(O.decrypt_bits(got[[cout]], s0, p)[0]) << bits
     assert total == x + y
+
+
+# ---- the 65,536-gate configuration at full size on one GPU ---------------------------------------
+
+def test_config3_65536_gates_decrypt_and_sampled_parity(keys, ctx, octx):
+    """All 65,536 outputs decrypt to NAND of the inputs; 48 gates spread over the batch (first and
+    last workgroups included) are bit-exact with the oracle."""
+    import torch
+
+    p, s0, _, _, _ = keys
+    G = 65536
+    rs = np.random.RandomState(2)           # the survey's generator for this configuration: seed 2
+    ba, bb = rs.randint(0, 2, G), rs.randint(0, 2, G)
+    r = O.rng(2)
+    a, b = O.encrypt_bits(ba, s0, p, r), O.encrypt_bits(bb, s0, p, r)
+    da, db = torch.from_numpy(a.view(np.int32)).cuda(), torch.from_numpy(b.view(np.int32)).cuda()
+    out = torch.empty_like(da)
+    ctx.nand_device(da, db, out)
+    ctx.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    s = s0.astype(np.uint32)
+    phase = got[:, 0] - (got[:, 1:] * s[None, :]).sum(axis=1, dtype=np.uint32)
+    assert np.array_equal((phase >> 31) == 0, (1 - (ba & bb)).astype(bool))
+    pick = np.unique(np.concatenate([np.arange(0, 8), np.arange(G - 8, G), rs.randint(0, G, 32)]))
+    assert np.array_equal(got[pick], octx.nand_batch(a[pick], b[pick]))
+
+
+def test_full_size_closed_form_on_noiseless_inputs(keys, ctx):
+    """Size-independent property at 65,536 gates: for a ciphertext with an all-zero mask every
+    rotation amount is zero, every decomposed difference is zero, so the blind rotation returns the
+    test vector rotated by -floor(b * 2N) exactly, whatever the key: acc_0[j] = +-1/8 with the sign
+    of the wrap-around, acc_1 = acc_2 = 0."""
+    import torch
+
+    p = keys[0]
+    G = 65536
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    c = torch.zeros((G, p.n + 1), dtype=torch.int32, device="cuda")
+    c[:, 0] = torch.randint(-2**31, 2**31 - 1, (G,), dtype=torch.int32, device="cuda", generator=gen)
+    lv1 = torch.empty((G, p.lv1 + 1), dtype=torch.int32, device="cuda")
+    ctx.gate_bootstrapping_tlwe_to_tlwe_device(c, lv1)
+    ctx.synchronize()
+    bbar = (c[:, 0].to(torch.int64) & 0xFFFFFFFF) >> 22                       # floor(b * 2N), in [0, 2N)
+    mu = 1 << 29
+    # acc_0[j] = sign(j + bbar) / 8; the extracted sample is [acc_0[0], acc_1[0], -acc_1[N-1..1], acc_2 ..]
+    want0 = torch.where((bbar & p.N) != 0, -mu, mu).to(torch.int32)
+    assert torch.equal(lv1[:, 0], want0)
+    assert not lv1[:, 1:].any()

@@ -40,3 +40,13 @@ t0 = time.time()
 ctx.nand(a, b)
 dt = time.time() - t0
 print(f"host-pointer nand, G={G}: {dt*1e3:.2f} ms  {G/dt:.0f} gates/s (PCIe inclusive, pageable host memory)", flush=True)
+
+# same call on page-locked host memory (torch pinned tensors viewed as numpy)
+ta = torch.from_numpy(a.view(np.int32)).pin_memory()
+tb = torch.from_numpy(b.view(np.int32)).pin_memory()
+pa, pb = ta.numpy().view(np.uint32), tb.numpy().view(np.uint32)
+ctx.nand(pa[:64], pb[:64])
+t0 = time.time()
+ctx.nand(pa, pb)
+dt = time.time() - t0
+print(f"host-pointer nand, G={G}: {dt*1e3:.2f} ms  {G/dt:.0f} gates/s (PCIe inclusive, page-locked inputs, pageable output)", flush=True)
