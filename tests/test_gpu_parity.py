@@ -265,7 +265,7 @@ def test_config3_65536_gates_decrypt_and_sampled_parity(keys, ctx, octx):
 
     p, s0, _, _, _ = keys
     G = 65536
-    rs = np.random.RandomState(2)           # the survey's generator for this configuration: seed 2
+    rs = np.random.RandomState(2)
     ba, bb = rs.randint(0, 2, G), rs.randint(0, 2, G)
     r = O.rng(2)
     a, b = O.encrypt_bits(ba, s0, p, r), O.encrypt_bits(bb, s0, p, r)
