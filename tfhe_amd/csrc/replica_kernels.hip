@@ -4,7 +4,8 @@
 // depending on the rounding of that FFT; a context created with TFHE_AMD_CTX_REFERENCE_FFT therefore
 // returns ciphertexts that are bit-identical to those of the reference compiled without FMA
 // contraction (g++ -O2 on x86-64, the reference's CI build), where the default exact NTT path
-// returns the exact ones.  Verification mode: one workgroup per gate, no attempt at speed.
+// returns the exact ones.  Two kernels: a parameter-generic one (one workgroup per gate, rings
+// 32 .. 1024) and, further down, a wave-per-gate one for the default parameter set.
 //
 // What is replayed (M = N/2): fold N reals into M complex numbers (first half real parts, second half
 // imaginary parts); twist by powers of e^(i pi / N) built by repeated multiplication; an M-point
