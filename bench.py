@@ -130,6 +130,8 @@ def main():
         t_bcast = time.time() - t0
     bk, ks = bk.to(dev), ks.to(dev)
     ctx = tfhe_amd.Context(p, bk, ks, device=dev_index, keys_on_device=True)
+    if ctx.kernel_family() != "ntt512":
+        raise SystemExit(f"bench: expected the NTT kernels of the default parameter set, got {ctx.kernel_family()}")
     # verification mode (products through a replay of the reference's FFT: output bit-identical to the
     # compiled reference), timed beside the default path on one GPU
     ctx_ref = None

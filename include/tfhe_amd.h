@@ -193,6 +193,12 @@ int tfhe_amd_external_product_batch(const tfhe_amd_params* p, const uint32_t* tr
 int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* d0, const uint32_t* d1,
                         uint32_t* out, size_t batch, int device);
 
+/* Which blind-rotation kernels a context uses: "ntt512" (default parameter set: wave-per-gate and
+ * workgroup-per-gate NTT kernels), "ntt-workgroup" (N = 2048 set), "generic" (exact O(N^2) kernels),
+ * "reference-fft-wave" / "reference-fft-workgroup" (verification mode), or "none" (no bootstrapping
+ * key).  For logs and for tests that must not pass on a slower path by accident. */
+const char* tfhe_amd_ctx_kernel_family(const tfhe_amd_ctx* ctx);
+
 /* Blocks until everything enqueued on the context's own stream has finished. */
 int tfhe_amd_ctx_synchronize(tfhe_amd_ctx* ctx);
 

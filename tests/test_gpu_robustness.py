@@ -174,3 +174,24 @@ def test_back_to_back_calls_on_two_streams_share_the_workspace_safely(keysets):
         pick1, pick2 = np.array([0, 1, 1150, 2299]), np.array([0, 299, 599])
         assert np.array_equal(g1[pick1], octx.nand_batch(a1[pick1], b1[pick1]))
         assert np.array_equal(g2[pick2], octx.nand_batch(a2[pick2], b2[pick2]))
+
+
+def test_each_parameter_set_runs_on_the_kernels_meant_for_it(keysets):
+    import tfhe_amd
+
+    p, (s0, sr, bk, ks), _ = keysets
+    dp = tfhe_amd.params_default()
+    cases = [({}, "ntt512"), ({"generic_kernels": True}, "generic"), ({"reference_fft": True}, "reference-fft-wave"),
+             ({"reference_fft": True, "generic_kernels": True}, "reference-fft-workgroup")]
+    for kw, want in cases:
+        with tfhe_amd.Context(dp, bk, ks, **kw) as ctx:
+            assert ctx.kernel_family() == want
+    with tfhe_amd.Context(dp, None, ks) as ctx:
+        assert ctx.kernel_family() == "none"
+    big = tfhe_amd.Params(800, 2048, 1, 8, 3, 8, 2)
+    rs = np.random.RandomState(0)
+    with tfhe_amd.Context(big, rs.randint(0, 2**32, size=big.bk_shape(), dtype=np.uint64).astype(np.uint32), None) as ctx:
+        assert ctx.kernel_family() == "ntt-workgroup"
+    toy = tfhe_amd.Params(10, 16, 2, 8, 2, 5, 2)
+    with tfhe_amd.Context(toy, rs.randint(0, 2**32, size=toy.bk_shape(), dtype=np.uint64).astype(np.uint32), None) as ctx:
+        assert ctx.kernel_family() == "generic"

@@ -110,6 +110,8 @@ def library():
     lib.tfhe_amd_identity_key_switch_batch_device.argtypes = [vp, vp, vp, sz, vp]
     lib.tfhe_amd_external_product_batch.argtypes = [pp, vp, vp, vp, sz, i32]
     lib.tfhe_amd_cmux_batch.argtypes = [pp, vp, vp, vp, vp, sz, i32]
+    lib.tfhe_amd_ctx_kernel_family.argtypes = [vp]
+    lib.tfhe_amd_ctx_kernel_family.restype = C.c_char_p
     lib.tfhe_amd_ctx_synchronize.argtypes = [vp]
     lib.tfhe_amd_ctx_enable_timing.argtypes = [vp, i32]
     lib.tfhe_amd_ctx_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -388,6 +390,10 @@ class Context:
             self._h, _dev_ptr(lv1, g * (self.params.lv1 + 1)), _dev_ptr(out, g * self.params.n1), g,
             self._stream_ptr(stream)))
         return out
+
+    def kernel_family(self):
+        """'ntt512', 'ntt-workgroup', 'generic', 'reference-fft-wave', 'reference-fft-workgroup' or 'none'."""
+        return library().tfhe_amd_ctx_kernel_family(self._h).decode()
 
     def synchronize(self):
         _check(library().tfhe_amd_ctx_synchronize(self._h))

@@ -875,6 +875,17 @@ int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const u
 
 // ---- housekeeping ----------------------------------------------------------------------------
 
+const char* tfhe_amd_ctx_kernel_family(const tfhe_amd_ctx* ctx) {
+    if (!ctx || !ctx->has_bk) return "none";
+    if (ctx->replica)
+        return (!ctx->replica_generic && replica_has_fast_kernel(ctx->p.N, ctx->p.K, ctx->p.L, ctx->p.bg_bit))
+                   ? "reference-fft-wave"
+                   : "reference-fft-workgroup";
+    if (ctx->fast) return "ntt512";
+    if (ctx->wg) return "ntt-workgroup";
+    return "generic";
+}
+
 int tfhe_amd_ctx_synchronize(tfhe_amd_ctx* ctx) {
     if (!ctx) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
     DeviceGuard guard(ctx->device);
