@@ -85,7 +85,31 @@ __device__ __forceinline__ void cx_group_first(Cx4& x, d2 w23) {
     cx_butterfly(x.re[2], x.im[2], x.re[3], x.im[3], w23);
 }
 
-// tr: two planes of kHalfTrWords doubles
+// Layout 1 -> layout 2 without the LDS: the element of lane L, point K goes to lane 16 K + (L & 15),
+// point L >> 4, a 4 x 4 transposition between the two point bits and lane bits 5 and 4, which the
+// half-wave and row swaps of gfx950 do in place (one instruction per 32-bit register pair).
+__device__ __forceinline__ void swap_half_waves(double& a, double& b) {  // a's lanes 32..63 <-> b's lanes 0..31
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap_rows(double& a, double& b) {  // a's odd 16-lane rows <-> b's even rows
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void cx_transpose_1_2(Cx4& x) {
+    swap_half_waves(x.re[0], x.re[2]); swap_half_waves(x.im[0], x.im[2]);
+    swap_half_waves(x.re[1], x.re[3]); swap_half_waves(x.im[1], x.im[3]);
+    swap_rows(x.re[0], x.re[1]); swap_rows(x.im[0], x.im[1]);
+    swap_rows(x.re[2], x.re[3]); swap_rows(x.im[2], x.im[3]);
+}
+
+// Transposition between layouts through the wave's LDS buffer tr (two planes of kHalfTrWords doubles:
+// real parts, imaginary parts).  The compiler waits for the loads only where their values are first
+// used, so independent work placed after the call overlaps the exchange.
 template <int FROM, int TO>
 __device__ __forceinline__ void cx_transpose(Cx4& x, double* tr, int lane) {
     constexpr int T = FROM < TO ? FROM : TO;
@@ -105,17 +129,32 @@ __device__ __forceinline__ void cx_transpose(Cx4& x, double* tr, int lane) {
     wave_lds_fence();
 }
 
-// In: layout 1 (position 64 k + lane).  Out: layout 4 (position 4 lane + k), i.e. natural index
-// bitrev8(4 lane + k).  rows: this direction's [85][3] table in LDS; w23 = its row 0, entry 2;
-// row2 = the lane's row of group 2 (four distinct rows per wave), kept in registers by the caller.
-__device__ __forceinline__ void fft256_wave(Cx4& x, const d2* rows, d2 w23, const d2 (&row2)[3], double* tr, int lane) {
-    cx_group_first(x, w23);
-    cx_transpose<1, 2>(x, tr, lane);
-    cx_group(x, row2);
-    cx_transpose<2, 3>(x, tr, lane);
-    cx_group(x, rows + 3 * (fft_row_offset(3) + fft_row<3>(lane)));
-    cx_transpose<3, 4>(x, tr, lane);
-    cx_group(x, rows + 3 * (fft_row_offset(4) + fft_row<4>(lane)));
+// Two independent transforms of the same direction, interleaved group by group: while one's
+// transposition is in flight in the LDS the other's butterflies run, so the wave does not sit out
+// the exchange latency.  In: layout 1 (position 64 k + lane).  Out: layout 4 (position 4 lane + k),
+// i.e. natural index bitrev8(4 lane + k).  rows: this direction's [85][3] table in LDS; w23 = its
+// row 0, entry 2; row2 = the lane's row of group 2; tra, trb: one transposition buffer each.
+__device__ __forceinline__ void fft256_wave2(Cx4& a, Cx4& b, const d2* rows, d2 w23, const d2* row2, double* tra,
+                                             double* trb, int lane) {
+    const d2* p3 = rows + 3 * (fft_row_offset(3) + fft_row<3>(lane));
+    const d2* p4 = rows + 3 * (fft_row_offset(4) + fft_row<4>(lane));
+    cx_group_first(a, w23);
+    cx_transpose_1_2(a);
+    const d2 r2[3] = {row2[0], row2[1], row2[2]};
+    cx_group_first(b, w23);
+    cx_transpose_1_2(b);
+    cx_group(a, r2);
+    cx_transpose<2, 3>(a, tra, lane);
+    const d2 r3[3] = {p3[0], p3[1], p3[2]};
+    cx_group(b, r2);
+    cx_transpose<2, 3>(b, trb, lane);
+    cx_group(a, r3);
+    cx_transpose<3, 4>(a, tra, lane);
+    const d2 r4[3] = {p4[0], p4[1], p4[2]};
+    cx_group(b, r3);
+    cx_transpose<3, 4>(b, trb, lane);
+    cx_group(a, r4);
+    cx_group(b, r4);
 }
 
 __device__ __forceinline__ int brev8(int v) { return (int)(__brev((unsigned)v) >> 24); }

@@ -50,7 +50,7 @@ __device__ __forceinline__ int half_row(int h, int lane) {
 }
 
 template <int LAYOUT>
-__device__ __forceinline__ int half_pos(int l, int k) {
+__host__ __device__ constexpr int half_pos(int l, int k) {
     if (LAYOUT == 1) return 64 * k + l;
     if (LAYOUT == 2) return 64 * (l >> 4) + 16 * k + (l & 15);
     if (LAYOUT == 3) return 16 * (l >> 2) + 4 * k + (l & 3);
@@ -60,7 +60,7 @@ __device__ __forceinline__ int half_pos(int l, int k) {
 // Padding of the transpose between layouts T and T + 1, chosen so that the 32 lanes of a pass
 // of an 8-byte LDS access fall on 32 different bank pairs in both layouts.
 template <int T>
-__device__ __forceinline__ int half_pad(int j) {
+__host__ __device__ constexpr int half_pad(int j) {
     if (T == 1) return j + 16 * (j >> 6);
     if (T == 2) return j + 4 * (j >> 4);
     return j + (j >> 2);

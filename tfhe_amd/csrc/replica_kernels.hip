@@ -77,7 +77,7 @@ struct RepShape {
 }  // namespace
 
 // Tables: [4][M] complex = twist powers, forward omega powers, untwist powers, reversed omega powers.
-// Key spectra: for every key polynomial, fft(twist(fold(poly / 2^32))) in natural order, [M] complex.
+// Key spectra: for every key polynomial, fft(twist(fold(poly / 2^32))) / M in natural order, [M] complex.
 __global__ void __launch_bounds__(kRepThreads)
 replica_key_kernel(const uint32_t* __restrict__ bk, const d2* __restrict__ tables, d2* __restrict__ spec, int N,
                    int bits) {
@@ -95,7 +95,15 @@ replica_key_kernel(const uint32_t* __restrict__ bk, const d2* __restrict__ table
         buf[i] = c_mul(v, tables[i]);
     }
     fft_block(buf, 1, M, bits, s_omega);
-    for (int i = threadIdx.x; i < M; i += kRepThreads) spec[poly * M + i] = buf[bitrev(i, bits)];
+    // The reference multiplies the second transform's output by 1/M, a power of two, which commutes
+    // exactly with every rounding in between: the factor is applied here, once per key.
+    const double scale = 1.0 / M;
+    for (int i = threadIdx.x; i < M; i += kRepThreads) {
+        d2 v = buf[bitrev(i, bits)];
+        v.x *= scale;
+        v.y *= scale;
+        spec[poly * M + i] = v;
+    }
 }
 
 // One workgroup per gate.  Same interface as blind_rotate_generic_kernel.
@@ -131,7 +139,6 @@ blind_rotate_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ 
     for (int l = 0; l < s.L; l++) off += 1u << (32 - s.bg * (l + 1) + s.bg - 1);
     const uint32_t mask = (1u << s.bg) - 1;
     const int half_digit = 1 << (s.bg - 1);
-    const double scale = 1.0 / M;
 
     for (int i = 0; i < n; i++) {
         const int abar = (int)((cg[1 + i] + (1u << (sh - 1))) >> sh);
@@ -163,10 +170,7 @@ blind_rotate_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ 
             for (int m = threadIdx.x; m < M; m += kRepThreads) {
                 uint32_t lo = 0, hi = 0;
                 for (int r = 0; r < R; r++) {
-                    d2 v = prod[r * M + bitrev(m, bits)];
-                    v.x *= scale;
-                    v.y *= scale;
-                    v = c_mul(v, s_untwist[m]);
+                    const d2 v = c_mul(prod[r * M + bitrev(m, bits)], s_untwist[m]);  // 1/M is in the key spectra
                     lo += torus_from_double_ref(v.x);
                     hi += torus_from_double_ref(v.y);
                 }
@@ -193,11 +197,14 @@ blind_rotate_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // The default parameter set (N = 512, K = 2, L = 2) at speed: one WAVE per gate, the reference's
 // 256-point transforms evaluated in registers (fft256_wave.hpp), same structure as
-// blind_rotate_512_kernel.  Per step and digit polynomial: fold and twist, forward transform,
-// permutation to natural order, then per column: pointwise product with the key spectrum, the
-// second transform, scale, untwist, truncating conversion of both parts, wrap-around sum.  The
-// reference rounds every product on its own, so there are (K+1) L (K+1) = 18 second transforms per
-// step where the exact path needs K + 1 = 3 inverse NTTs.
+// blind_rotate_512_kernel.  Per step and accumulator polynomial q the two digit polynomials
+// (levels 0 and 1) run as one interleaved pair of transforms: fold and twist, forward transforms,
+// permutation to natural order, then per column: pointwise products with the two key spectra (which
+// carry the 1/M factor), the pair of second transforms, untwist, truncating conversion of both
+// parts, wrap-around sum.  The reference rounds every product on its own, so there are
+// (K+1) L (K+1) = 18 second transforms per step where the exact path needs K + 1 = 3 inverse NTTs.
+// Pairing hides the LDS latency of one transform's transposition behind the other's butterflies;
+// the first transposition of every transform stays in registers (half-wave and row swaps).
 // tables: the [4][256] base tables followed by the block described in fft256_wave.hpp.
 // ------------------------------------------------------------------------------------------
 template <int K, int L>
@@ -205,24 +212,22 @@ __global__ void __launch_bounds__(256, 2)
 blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ tables,
                                 const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv,
                                 uint32_t* __restrict__ out, int n_gates, int n, int extract) {
+    static_assert(L == 2, "the two levels of a digit polynomial run as one interleaved pair of transforms");
     constexpr int K1 = K + 1, R = K1 * L, BG = 8, M = 256;
     __shared__ d2 s_rows[2 * kFftRows * 3];
-    __shared__ d2 s_twist[M];
-    __shared__ d2 s_untwist[M];  // position order: entry m belongs to natural index bitrev8(m)
-    __shared__ double s_tr[4][2 * kHalfTrWords];
+    __shared__ d2 s_untwist[M];  // entry 64 k + lane: the power for position 4 lane + k, natural index bitrev8(4 lane + k)
+    __shared__ double s_tr[4][2][2 * kHalfTrWords];
     __shared__ uint32_t s_acc[4][K1][kN];
 
     for (int i = threadIdx.x; i < 2 * kFftRows * 3; i += 256) s_rows[i] = tables[4 * M + i];
-    for (int i = threadIdx.x; i < M; i += 256) {
-        s_twist[i] = tables[i];
-        s_untwist[i] = tables[4 * M + kFftUntwistPos + i];
-    }
+    for (int i = threadIdx.x; i < M; i += 256) s_untwist[i] = tables[4 * M + kFftUntwistPos + 4 * (i & 63) + (i >> 6)];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gate = blockIdx.x * 4 + wave;
     if (gate >= n_gates) return;  // waves are independent from here on
-    double* tr = s_tr[wave];
+    double* tr0 = s_tr[wave][0];
+    double* tr1 = s_tr[wave][1];
     uint32_t(*acc)[kN] = s_acc[wave];
     const uint32_t* cg = c + (size_t)gate * (n + 1);
     const d2* rows_fwd = s_rows + kFftFwdRows;
@@ -248,29 +253,13 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
         offset += 1u << (32 - BG * (l + 1) + BG - 1);
         flip |= 1u << (32 - BG * (l + 1) + BG - 1);
     }
-    d2 twist[4], untwist[4];
     int nat[4];  // natural index of position 4 lane + k
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        twist[k] = s_twist[64 * k + lane];
-        untwist[k] = s_untwist[4 * lane + k];
-        nat[k] = brev8(4 * lane + k);
-    }
-    // The reference scales by 1/M = 2^-8 and then multiplies by the untwist power; a power of two
-    // commutes exactly with every later rounding, so it is folded into the power.
-    const double scale = 1.0 / M;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        untwist[k].x *= scale;
-        untwist[k].y *= scale;
-    }
+    for (int k = 0; k < 4; k++) nat[k] = brev8(4 * lane + k);
     const d2 w23_fwd = rows_fwd[2], w23_inv = rows_inv[2];
-    d2 row2_fwd[3], row2_inv[3];
-#pragma unroll
-    for (int e = 0; e < 3; e++) {
-        row2_fwd[e] = rows_fwd[3 * (fft_row_offset(2) + fft_row<2>(lane)) + e];
-        row2_inv[e] = rows_inv[3 * (fft_row_offset(2) + fft_row<2>(lane)) + e];
-    }
+    const d2* row2_fwd = rows_fwd + 3 * (fft_row_offset(2) + fft_row<2>(lane));
+    const d2* row2_inv = rows_inv + 3 * (fft_row_offset(2) + fft_row<2>(lane));
+    const d2* twist = tables + lane;  // powers for the points 64 k + lane
 
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
@@ -287,6 +276,15 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
         const d2* key_row = spec + (size_t)i * (R * K1 * M);
 #pragma unroll 1
         for (int q = 0; q < K1; q++) {
+            // spectra of the key polynomials (q, level 0) and (q, level 1), column 0
+            const d2* key0 = key_row + (size_t)(q * L) * K1 * M;
+            const d2* key1 = key0 + (size_t)K1 * M;
+            d2 y0[4], y1[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                y0[k] = key0[64 * k + lane];
+                y1[k] = key1[64 * k + lane];
+            }
             uint32_t t[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -295,44 +293,56 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                 const uint32_t v = acc[q][sidx & (kN - 1)];
                 t[k] = ((((v ^ neg) - neg) - acc[q][64 * k + lane]) + offset) ^ flip;
             }
-#pragma unroll 1
-            for (int level = 0; level < L; level++) {
-                const d2* key = key_row + (size_t)(q * L + level) * K1 * M;
-                d2 y[K1][4];
+            // fold (real part: coefficient m, imaginary part: coefficient m + 256) and twist, both levels
+            Cx4 x0, x1;
 #pragma unroll
-                for (int col = 0; col < K1; col++)
+            for (int k = 0; k < 4; k++) {
+                const d2 tw = twist[64 * k];
+                const double dr0 = (double)(((int32_t)t[k]) >> (32 - BG));
+                const double di0 = (double)(((int32_t)t[k + 4]) >> (32 - BG));
+                const double dr1 = (double)(((int32_t)(t[k] << BG)) >> (32 - BG));
+                const double di1 = (double)(((int32_t)(t[k + 4] << BG)) >> (32 - BG));
+                const double ac0 = dr0 * tw.x, bd0 = di0 * tw.y, ad0 = dr0 * tw.y, bc0 = di0 * tw.x;
+                const double ac1 = dr1 * tw.x, bd1 = di1 * tw.y, ad1 = dr1 * tw.y, bc1 = di1 * tw.x;
+                x0.re[k] = ac0 - bd0;
+                x0.im[k] = ad0 + bc0;
+                x1.re[k] = ac1 - bd1;
+                x1.im[k] = ad1 + bc1;
+            }
+            fft256_wave2(x0, x1, rows_fwd, w23_fwd, row2_fwd, tr0, tr1, lane);
+            cx_to_natural(x0, tr0, lane);
+            cx_to_natural(x1, tr1, lane);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) y[col][k] = key[col * M + 64 * k + lane];
-                // fold (real part: coefficient m, imaginary part: coefficient m + 256) and twist
-                Cx4 x;
+            for (int col = 0; col < K1; col++) {
+                Cx4 p0, p1;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const double dr = (double)(((int32_t)(t[k] << (BG * level))) >> (32 - BG));
-                    const double di = (double)(((int32_t)(t[k + 4] << (BG * level))) >> (32 - BG));
-                    const double ac = dr * twist[k].x, bd = di * twist[k].y, ad = dr * twist[k].y, bc = di * twist[k].x;
-                    x.re[k] = ac - bd;
-                    x.im[k] = ad + bc;
+                    const double ac0 = x0.re[k] * y0[k].x, bd0 = x0.im[k] * y0[k].y;
+                    const double ad0 = x0.re[k] * y0[k].y, bc0 = x0.im[k] * y0[k].x;
+                    const double ac1 = x1.re[k] * y1[k].x, bd1 = x1.im[k] * y1[k].y;
+                    const double ad1 = x1.re[k] * y1[k].y, bc1 = x1.im[k] * y1[k].x;
+                    p0.re[k] = ac0 - bd0;
+                    p0.im[k] = ad0 + bc0;
+                    p1.re[k] = ac1 - bd1;
+                    p1.im[k] = ad1 + bc1;
                 }
-                fft256_wave(x, rows_fwd, w23_fwd, row2_fwd, tr, lane);
-                cx_to_natural(x, tr, lane);
-#pragma unroll
-                for (int col = 0; col < K1; col++) {
-                    Cx4 pr;
+                if (col + 1 < K1) {  // the next column's spectra arrive behind this column's transforms
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const double ac = x.re[k] * y[col][k].x, bd = x.im[k] * y[col][k].y;
-                        const double ad = x.re[k] * y[col][k].y, bc = x.im[k] * y[col][k].x;
-                        pr.re[k] = ac - bd;
-                        pr.im[k] = ad + bc;
+                        y0[k] = key0[(col + 1) * M + 64 * k + lane];
+                        y1[k] = key1[(col + 1) * M + 64 * k + lane];
                     }
-                    fft256_wave(pr, rows_inv, w23_inv, row2_inv, tr, lane);
+                }
+                fft256_wave2(p0, p1, rows_inv, w23_inv, row2_inv, tr0, tr1, lane);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const double ac = pr.re[k] * untwist[k].x, bd = pr.im[k] * untwist[k].y;
-                        const double ad = pr.re[k] * untwist[k].y, bc = pr.im[k] * untwist[k].x;
-                        lo[col][k] += torus_from_double_fast(ac - bd);
-                        hi[col][k] += torus_from_double_fast(ad + bc);
-                    }
+                for (int k = 0; k < 4; k++) {
+                    const d2 u = s_untwist[64 * k + lane];
+                    const double ac0 = p0.re[k] * u.x, bd0 = p0.im[k] * u.y;
+                    const double ad0 = p0.re[k] * u.y, bc0 = p0.im[k] * u.x;
+                    const double ac1 = p1.re[k] * u.x, bd1 = p1.im[k] * u.y;
+                    const double ad1 = p1.re[k] * u.y, bc1 = p1.im[k] * u.x;
+                    lo[col][k] += torus_from_double_fast(ac0 - bd0) + torus_from_double_fast(ac1 - bd1);
+                    hi[col][k] += torus_from_double_fast(ad0 + bc0) + torus_from_double_fast(ad1 + bc1);
                 }
             }
         }
