@@ -127,6 +127,9 @@ __global__ void __launch_bounds__(256) bk_transform_512_kernel(const NttUniform 
 // Phase-ordered butterflies (ntt512.hpp) in the throughput form.  Measured on 8,192 gates:
 // 47.6 -> 46.3 ms (two waves per SIMD still leave dependent-issue gaps).
 constexpr bool kPinThroughput = TFHE_AMD_PIN_THROUGHPUT != 0;
+#ifndef TFHE_AMD_PAIR_THROUGHPUT
+#define TFHE_AMD_PAIR_THROUGHPUT 1
+#endif
 
 template <int K, int L>
 __global__ void __launch_bounds__(256, 2)
@@ -135,7 +138,7 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
                         int n_gates, int n, int extract) {
     constexpr int K1 = K + 1, R = K1 * L, BG = 8;
     __shared__ d2 s_tw[kTwPairs];
-    __shared__ double s_tr[4][kTrPad];
+    __shared__ double s_tr[4][TFHE_AMD_PAIR_THROUGHPUT ? 2 : 1][kTrPad];
     __shared__ uint32_t s_acc[4][K1][kN];
 
     for (int i = threadIdx.x; i < kTwPairs; i += 256) s_tw[i] = tw[i];
@@ -145,7 +148,8 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
     const int gate = blockIdx.x * 4 + wave;
     if (gate >= n_gates) return;  // waves are independent from here on: no further block barrier
 
-    double* tr = s_tr[wave];
+    double* tr = s_tr[wave][0];
+    double* tr2 = s_tr[wave][TFHE_AMD_PAIR_THROUGHPUT ? 1 : 0];
     uint32_t(*acc)[kN] = s_acc[wave];
     const uint32_t* cg = c + (size_t)gate * (n + 1);
     const double p = u.p, pinv = u.pinv;
@@ -209,6 +213,56 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
                 const uint32_t v = acc[q][src[k]];
                 t[k] = ((((v ^ neg[k]) - neg[k]) - acc[q][64 * k + lane]) + offset) ^ flip;
             }
+#if TFHE_AMD_PAIR_THROUGHPUT
+            {
+                static_assert(L == 2 && K1 == 3, "the two levels of a digit polynomial run as one interleaved pair");
+                double x0[8], x1[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    x0[k] = (double)(((int32_t)t[k]) >> (32 - BG));
+                    x1[k] = (double)(((int32_t)(t[k] << BG)) >> (32 - BG));
+                }
+                const d2* bk_poly = bk_row + (size_t)(q * L) * K1 * (kN / 2);
+                d2 y[K1][4];
+#pragma unroll
+                for (int col = 0; col < K1; col++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) y[col][kk] = bk_poly[col * (kN / 2) + kk * 64 + lane];
+                auto mac = [&](double (&x)[8]) {
+#pragma unroll
+                    for (int col = 0; col < K1; col++) {
+                        double yy[8], prod[8];
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            yy[2 * kk] = y[col][kk].x;
+                            yy[2 * kk + 1] = y[col][kk].y;
+                        }
+                        mulmod_var_n<8>(prod, x, yy, p, pinv);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) out[col][k] += prod[k];
+                    }
+                };
+                ntt512_forward2_small(x0, x1, u, s_tw, tr, tr2, lane, [&]() {
+                    mac(x0);
+                    // every product is at most 1.41 p: three sum to <= 4.24 p; reducing after the third
+                    // of the six keeps the running sum below 0.5 p + 4.24 p = 4.74 p < 2^53 = 5.26 p
+                    if (q == 1) {
+#pragma unroll
+                        for (int col = 0; col < K1; col++)
+#pragma unroll
+                            for (int k = 0; k < 8; k++) out[col][k] = reduce(out[col][k], p, pinv);
+                    }
+                    // level 1's key row replaces level 0's in the same registers; its latency hides
+                    // under the last stage group of x1
+#pragma unroll
+                    for (int col = 0; col < K1; col++)
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++)
+                            y[col][kk] = bk_poly[(K1 + col) * (kN / 2) + kk * 64 + lane];
+                });
+                mac(x1);
+            }
+#else
 #pragma unroll
             for (int level = 0; level < L; level++) {
                 double x[8];
@@ -254,14 +308,25 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
                         for (int k = 0; k < 8; k++) out[col][k] = reduce(out[col][k], p, pinv);
                 }
             }
+#endif
         }
         // |out| <= 4.74 p
+#if TFHE_AMD_PAIR_THROUGHPUT
+        static_assert(K1 == 3, "inverse transforms run as one pair and one single");
+        ntt512_inverse2(out[0], out[1], u, s_tw, tr, tr2, lane);
+        ntt512_inverse<true>(out[2], u, s_tw, tr, lane);
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[col][64 * k + lane] += to_torus(out[col][k], p, pinv);
+#else
 #pragma unroll
         for (int col = 0; col < K1; col++) {
             ntt512_inverse<kPinThroughput>(out[col], u, s_tw, tr, lane);
 #pragma unroll
             for (int k = 0; k < 8; k++) acc[col][64 * k + lane] += to_torus(out[col][k], p, pinv);
         }
+#endif
         wave_lds_fence();
     }
 

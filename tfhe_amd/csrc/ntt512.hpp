@@ -398,6 +398,87 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform&
     }
 }
 
+// First stage group of the forward transform of 8-bit digits (layout A), phase-ordered: the
+// distance-256 and the first distance-128 twiddles are small enough to need no reduction.
+__device__ __forceinline__ void ct8_small_first(double (&x)[8], const NttUniform& u) {
+    const double p = u.p, pinv = u.pinv;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double a = x[k], b = x[k + 4];
+        x[k] = __builtin_fma(b, u.zI, a);
+        x[k + 4] = __builtin_fma(-b, u.zI, a);
+    }
+    pin();
+    double b2[2], w2[2], wp2[2], t2[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double a = x[k], b = x[k + 2];
+        x[k] = __builtin_fma(b, u.z, a);
+        x[k + 2] = __builtin_fma(-b, u.z, a);
+        b2[k] = x[k + 6];
+        w2[k] = u.fw[3];
+        wp2[k] = u.fwp[3];
+    }
+    mulmod_tw_n<2>(t2, b2, w2, wp2, p);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double a = x[k + 4];
+        x[k + 6] = a - t2[k];
+        x[k + 4] = a + t2[k];
+    }
+    pin();
+    ct_stage_pinned<1, false>(x, u.fw + 1, u.fwp + 1, p, pinv);
+}
+
+// Two forward transforms of 8-bit digit polynomials, interleaved group by group so that one's
+// butterflies run while the other's transposition is in flight (tra, trb: a buffer each).  Same
+// arithmetic and bounds as ntt512_forward<true, false, true>.  Between the last group of a and the
+// last group of b the caller's `between(a)` runs: a is complete there, b's transposition in flight.
+template <typename Between>
+__device__ __forceinline__ void ntt512_forward2_small(double (&a)[8], double (&b)[8], const NttUniform& u, const d2* s_tw,
+                                                      double* tra, double* trb, int lane, Between between) {
+    const double p = u.p, pinv = u.pinv;
+    ct8_small_first(a, u);
+    transpose_a_to_b(a, tra, lane);
+    ct8_small_first(b, u);
+    transpose_a_to_b(b, trb, lane);
+    Tw7 t;
+    load_tw7(t, s_tw + kTwFwdB + 7 * (lane >> 3));
+    ct8_pinned<false>(a, t.w, t.wp, p, pinv);
+    transpose_b_to_c(a, tra, lane);
+    ct8_pinned<false>(b, t.w, t.wp, p, pinv);
+    transpose_b_to_c(b, trb, lane);
+    load_tw7(t, s_tw + kTwFwdC + 7 * lane);
+    ct8_pinned<true>(a, t.w, t.wp, p, pinv);
+    between();
+    ct8_pinned<true>(b, t.w, t.wp, p, pinv);
+}
+
+// Two inverse transforms interleaved the same way; arithmetic and bounds of ntt512_inverse<true>.
+__device__ __forceinline__ void ntt512_inverse2(double (&a)[8], double (&b)[8], const NttUniform& u, const d2* s_tw,
+                                                double* tra, double* trb, int lane) {
+    const double p = u.p, pinv = u.pinv;
+    Tw7 t;
+    load_tw7(t, s_tw + kTwInvC + 7 * lane);
+    reduce_n<8>(a, p, pinv);
+    gs8_pinned(a, t.w, t.wp, p);
+    transpose_c_to_b(a, tra, lane);
+    reduce_n<8>(b, p, pinv);
+    gs8_pinned(b, t.w, t.wp, p);
+    transpose_c_to_b(b, trb, lane);
+    load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
+    reduce_n<8>(a, p, pinv);
+    gs8_pinned(a, t.w, t.wp, p);
+    transpose_b_to_a(a, tra, lane);
+    reduce_n<8>(b, p, pinv);
+    gs8_pinned(b, t.w, t.wp, p);
+    transpose_b_to_a(b, trb, lane);
+    reduce_n<8>(a, p, pinv);
+    gs8_pinned(a, u.iw + 1, u.iwp + 1, p);
+    reduce_n<8>(b, p, pinv);
+    gs8_pinned(b, u.iw + 1, u.iwp + 1, p);
+}
+
 // Inverse transform without the 1/N factor.  In: layout C, |x| < 2^53.  Out: layout A,
 // |x| <= 4 p.  Every group of three GS stages starts from |x| <= p/2 and doubles the bound
 // of the sum outputs at most three times.
