@@ -195,3 +195,32 @@ def test_each_parameter_set_runs_on_the_kernels_meant_for_it(keysets):
     toy = tfhe_amd.Params(10, 16, 2, 8, 2, 5, 2)
     with tfhe_amd.Context(toy, rs.randint(0, 2**32, size=toy.bk_shape(), dtype=np.uint64).astype(np.uint32), None) as ctx:
         assert ctx.kernel_family() == "generic"
+
+
+def test_host_pointer_calls_return_what_device_resident_calls_return(keysets):
+    """A batch that is not a multiple of anything the kernels tile by (gates in flight, key-switch
+    tiles), through the host-pointer entry points and through the device-pointer ones."""
+    import torch
+
+    import tfhe_amd
+
+    p, (s0, sr, bk, ks), _ = keysets
+    n = 2 * 2048 + 700
+    rs = np.random.RandomState(5)
+    a, b, x0 = (rs.randint(0, 2**32, size=(n, p.n + 1), dtype=np.uint64).astype(np.uint32) for _ in range(3))
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks) as ctx:
+        da, db, dx = (torch.from_numpy(v.view(np.int32)).cuda() for v in (a, b, x0))
+        out = torch.empty_like(da)
+        ctx.nand_device(da, db, out)
+        ctx.synchronize()
+        assert np.array_equal(ctx.nand(a, b), out.cpu().numpy().view(np.uint32))
+        ctx.gate_device("xor", da, db, out)
+        ctx.synchronize()
+        assert np.array_equal(ctx.gate("xor", a, b), out.cpu().numpy().view(np.uint32))
+        ctx.mux_device(da, db, dx, out)
+        ctx.synchronize()
+        assert np.array_equal(ctx.mux(a, b, x0), out.cpu().numpy().view(np.uint32))
+        # and against the oracle on a sample of rows
+        octx = O.Context(p, bk, ks)
+        rows = np.array([0, 2047, 2048, 4095, 4096, n - 1])
+        assert np.array_equal(ctx.nand(a, b)[rows], octx.nand_batch(a[rows], b[rows]))
