@@ -518,19 +518,20 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
 // rows dropped and every row padded to ROWP (a multiple of 320 words) so that rows are
 // 16-byte aligned and the rows of one lv1 coefficient are one contiguous block.
 //
-// Work split: a workgroup (5 waves) owns a tile of 64 gates, a slab of 320 output words and
+// Work split: a workgroup (4 waves) owns a tile of 64 gates, a slab of 320 output words and
 // one of `parts` equal slices of the lv1 coefficients.  Lane = gate; wave v accumulates words
-// [64 v, 64 v + 64) of the slab for its 64 gates in registers.  The slab's share of the rows
+// [80 v, 80 v + 80) of the slab for its 64 gates in registers.  The slab's share of the rows
 // of MG consecutive levels m of one coefficient i is staged in LDS (double buffered, behind
 // one all-zero row); per level every lane turns its own digit into a row address (digit 0 ->
-// the zero row, which is what the reference's `if (o)` amounts to) and reads its 64 words with
-// sixteen 16-byte LDS reads.  Rows are 324 words apart in LDS so that the (at most 2^bb)
+// the zero row, which is what the reference's `if (o)` amounts to) and reads its 80 words with
+// twenty 16-byte LDS reads.  Rows are 324 words apart in LDS so that the (at most 2^bb)
 // different rows a 16-lane group touches fall on different banks.  There is no scalar
 // selection and one LDS round trip per level.  With parts > 1 the slices are combined with
 // integer atomic adds into the zero-initialised output; wrap-around addition is associative,
 // so the result does not depend on arrival order.
 // ------------------------------------------------------------------------------------------
-constexpr int kKsThreads = 320;   // 5 waves
+constexpr int kKsThreads = 256;   // 4 waves, one per SIMD: five waves of 64 words leave the SIMD that gets two the bottleneck
+constexpr int kKsWaveWords = 80;  // output words per wave
 constexpr int kKsSlab = 320;      // output words per workgroup
 constexpr int kKsRowLds = 324;    // LDS row stride in words: 320 + 4 (bank skew between rows)
 constexpr int kKsChunk = 64;      // lv1 coefficients whose digits are resident at a time
@@ -549,7 +550,7 @@ ks_pack_kernel(uint32_t* __restrict__ packed, const uint32_t* __restrict__ ks, s
 }
 
 template <int NR1, int MG>
-__global__ void __launch_bounds__(kKsThreads, 3)
+__global__ void __launch_bounds__(kKsThreads, 2)
 key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__ ks_packed,
                   uint32_t* __restrict__ out, int n_gates, int n1, int nlv1, int T, int bb, int rowp, int parts) {
     constexpr int SR = MG * NR1;                          // rows per stage
@@ -571,15 +572,16 @@ key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__
     const int dshift = 32 - T * bb;
     const uint32_t omask = (1u << bb) - 1;
 
-    uint32_t acc[64];
+    static_assert(kKsWaveWords * (kKsThreads / 64) == kKsSlab && kKsWaveWords % 40 == 0, "slab split over the waves");
+    uint32_t acc[kKsWaveWords];
 #pragma unroll
-    for (int k = 0; k < 64; k++) acc[k] = 0u;
+    for (int k = 0; k < kKsWaveWords; k++) acc[k] = 0u;
     for (int w = tid; w < kKsRowLds; w += kKsThreads) s_zero[w] = 0u;
 
     const int stages_per_i = T / MG;
     const int total = (i_end - i_begin) * stages_per_i;
-    static_assert(PRE <= 4, "stage too large for the prefetch registers");
-    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {};
+    static_assert(PRE <= 5, "stage too large for the prefetch registers");
+    uint4 pre0 = {}, pre1 = {}, pre2 = {}, pre3 = {}, pre4 = {};
     // threads past the end of the stage re-read its last vector (never stored)
 #define KS_LOAD1(Q, DST)                                                                       \
     if (Q < PRE) {                                                                             \
@@ -591,7 +593,7 @@ key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__
     {                                                                                          \
         const int pi_ = i_begin + (ST) / stages_per_i, pm_ = ((ST) % stages_per_i) * MG;       \
         const uint32_t* src_ = ks_packed + ((size_t)pi_ * T + pm_) * NR1 * rowp + slab * kKsSlab; \
-        KS_LOAD1(0, pre0) KS_LOAD1(1, pre1) KS_LOAD1(2, pre2) KS_LOAD1(3, pre3)                \
+        KS_LOAD1(0, pre0) KS_LOAD1(1, pre1) KS_LOAD1(2, pre2) KS_LOAD1(3, pre3) KS_LOAD1(4, pre4) \
     }
 #define KS_STORE1(Q, SRC)                                                                      \
     if (Q < PRE) {                                                                             \
@@ -616,38 +618,39 @@ key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__
             }
         }
         uint32_t* buf = s_rows + (st & 1) * BUF;
-        KS_STORE1(0, pre0) KS_STORE1(1, pre1) KS_STORE1(2, pre2) KS_STORE1(3, pre3)
+        KS_STORE1(0, pre0) KS_STORE1(1, pre1) KS_STORE1(2, pre2) KS_STORE1(3, pre3) KS_STORE1(4, pre4)
         __syncthreads();  // stage st is in LDS; all reads of stage st-1 precede the next write of its buffer
         if (st + 1 < total) KS_PREFETCH(st + 1)
 
         const uint32_t d = s_dig[(irel % kKsChunk) * kKsTile + lane];
-        // byte offsets from s_zero: word 64*wave of the zero row, or of row (mm*NR1 + o - 1) of buf
-        const int zero_off = 4 * 64 * wave;
-        const int buf_off = 4 * ((int)(buf - s_zero) + 64 * wave);
+        // byte offsets from s_zero: this wave's first word of the zero row, or of row (mm*NR1 + o - 1) of buf
+        const int zero_off = 4 * kKsWaveWords * wave;
+        const int buf_off = 4 * ((int)(buf - s_zero) + kKsWaveWords * wave);
         const char* base = reinterpret_cast<const char*>(s_zero);
 #pragma unroll
         for (int mm = 0; mm < MG; mm++) {
             const uint32_t o = (d >> ((T - 1 - (m0 + mm)) * bb)) & omask;
             const int off = o ? buf_off + 4 * kKsRowLds * (mm * NR1 + (int)o - 1) : zero_off;
             const uint4* row = reinterpret_cast<const uint4*>(base + off);
-            // two batches of eight 16-byte reads; the scheduling barriers keep the compiler from
-            // hoisting later batches' reads (and their 32 registers each) above this one
+            // two batches of ten 16-byte reads; the scheduling barriers keep the compiler from
+            // hoisting later batches' reads (and their 40 registers each) above this one
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                uint4 v[8];
+                constexpr int HW = kKsWaveWords / 2, HV = HW / 4;
+                uint4 v[HV];
 #pragma unroll
-                for (int q = 0; q < 8; q++) v[q] = row[8 * h + q];
+                for (int q = 0; q < HV; q++) v[q] = row[HV * h + q];
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    acc[32 * h + 4 * q] -= v[q].x;
-                    acc[32 * h + 4 * q + 1] -= v[q].y;
-                    acc[32 * h + 4 * q + 2] -= v[q].z;
-                    acc[32 * h + 4 * q + 3] -= v[q].w;
+                for (int q = 0; q < HV; q++) {
+                    acc[HW * h + 4 * q] -= v[q].x;
+                    acc[HW * h + 4 * q + 1] -= v[q].y;
+                    acc[HW * h + 4 * q + 2] -= v[q].z;
+                    acc[HW * h + 4 * q + 3] -= v[q].w;
                 }
                 // opaque to the optimiser: stops it from summing several levels' rows first
                 // (which would keep all of them live) before touching the accumulators
 #pragma unroll
-                for (int k = 0; k < 32; k++) asm volatile("" : "+v"(acc[32 * h + k]));
+                for (int k = 0; k < HW; k++) asm volatile("" : "+v"(acc[HW * h + k]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -661,9 +664,9 @@ key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__
     // consecutive lanes touch consecutive words.
     __syncthreads();
     uint32_t* s_t = s_mem + wave * (64 * 17);
-    const int wbase = slab * kKsSlab + 64 * wave;
+    const int wbase = slab * kKsSlab + kKsWaveWords * wave;
 #pragma unroll
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < kKsWaveWords / 16; pass++) {
 #pragma unroll
         for (int k = 0; k < 16; k++) s_t[lane * 17 + k] = acc[16 * pass + k];
         wave_lds_fence();
