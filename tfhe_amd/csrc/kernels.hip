@@ -6,7 +6,10 @@
 //                                                                    reference src/trgsw.hpp:131-182,
 //                                                                    src/trlwe.hpp:109-122
 //   key_switch_kernel       identity key switch, a tile of gates per workgroup
+//   key_switch_small_kernel the same for a handful of gates, one workgroup per (gate, slice)
 //                                                                    reference src/tlwe_key_switching.hpp:47-65
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "ntt512.hpp"
 #include "ntt512_half.hpp"
@@ -687,6 +690,66 @@ key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// Identity key switch of a handful of gates, where the tiled kernel above would leave most of the
+// GPU idle (a tile is 64 gates): one workgroup per (gate, slice of the lv1 coefficients), thread =
+// two output words, so every row of the packed table is read with coalesced loads straight from
+// L2 / Infinity Cache.  Digit 0 reads a row anyway and masks it (the loads of a coefficient's T
+// levels are then independent of the digits and all in flight together).  Slices are combined with
+// integer atomic adds into the zero-initialised output, like the slices of the tiled kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kKsSmallThreads = 320;
+constexpr int kKsSmallMaxSlice = 64;  // lv1 coefficients per workgroup at most
+#ifndef TFHE_AMD_KS_SMALL_MAX_GATES
+#define TFHE_AMD_KS_SMALL_MAX_GATES 64
+#endif
+// larger batches take the tiled kernel (measured: 0.10 against 0.13 ms at 64 gates, 0.18 against 0.14 ms at 128)
+constexpr int kKsSmallMaxGates = TFHE_AMD_KS_SMALL_MAX_GATES;
+
+template <int T, int BB>
+__global__ void __launch_bounds__(kKsSmallThreads)
+key_switch_small_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__ ks_packed,
+                        uint32_t* __restrict__ out, int n1, int nlv1, int rowp, int slices) {
+    constexpr int NR1 = (1 << BB) - 1;
+    __shared__ uint32_t s_dig[kKsSmallMaxSlice];
+    const int g = blockIdx.x / slices, part = blockIdx.x % slices;
+    const int i_begin = (int)((long)nlv1 * part / slices), i_end = (int)((long)nlv1 * (part + 1) / slices);
+    const int count = i_end - i_begin, t = threadIdx.x;
+    const uint32_t* lv1_g = lv1 + (size_t)g * (nlv1 + 1);
+    const uint32_t round_offset = 1u << (32 - T * BB - 1);
+    if (t < count) s_dig[t] = (lv1_g[1 + i_begin + t] + round_offset) >> (32 - T * BB);
+    __syncthreads();
+    // words t and t + 320 of every row (rowp is a multiple of 320; rows are zero-padded beyond n1)
+    const int words = rowp / kKsSmallThreads;
+    for (int wi = 0; wi < words; wi += 2) {
+        const bool two = wi + 1 < words;
+        uint32_t acc0 = 0u, acc1 = 0u;
+        const uint32_t* col = ks_packed + (size_t)i_begin * T * NR1 * rowp + wi * kKsSmallThreads + t;
+#pragma unroll 2
+        for (int ii = 0; ii < count; ii++) {
+            const uint32_t d = s_dig[ii];
+            const uint32_t* rows_i = col + (size_t)ii * T * NR1 * rowp;
+#pragma unroll
+            for (int m = 0; m < T; m++) {
+                const uint32_t o = (d >> ((T - 1 - m) * BB)) & (uint32_t)NR1;
+                const uint32_t* row = rows_i + (size_t)(m * NR1 + (o ? (int)o - 1 : 0)) * rowp;
+                const uint32_t keep = o ? ~0u : 0u;
+                acc0 += row[0] & keep;
+                if (two) acc1 += row[kKsSmallThreads] & keep;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int word = (wi + h) * kKsSmallThreads + t;
+            if ((h == 0 || two) && word < n1) {
+                uint32_t v = 0u - (h ? acc1 : acc0);
+                if (word == 0 && part == 0) v += lv1_g[0];
+                if (v != 0u) atomicAdd(out + (size_t)g * n1 + word, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 hipError_t launch_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, size_t n_gates, int n1,
@@ -788,6 +851,18 @@ hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks_packed, uin
                              int nlv1, int T, int bb, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
     if (!key_switch_has_kernel(n1, T, bb)) return hipErrorInvalidValue;
+    // a handful of gates at the default decomposition: one workgroup per (gate, slice), enough
+    // slices to put about a thousand workgroups on the GPU
+    if (n_gates <= kKsSmallMaxGates && T == 5 && bb == 2 && nlv1 >= 8) {
+        int slices = 1024 / n_gates;
+        slices = std::min(slices, nlv1 / 8);
+        slices = std::max(slices, (nlv1 + kKsSmallMaxSlice - 1) / kKsSmallMaxSlice);
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)n_gates * n1 * sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        key_switch_small_kernel<5, 2><<<(unsigned)(n_gates * slices), kKsSmallThreads, 0, stream>>>(
+            lv1, ks_packed, out, n1, nlv1, key_switch_row_words(n1), slices);
+        return hipGetLastError();
+    }
     // MG levels per LDS stage: the largest instantiated divisor of T
 #define KS_GO(NR1, MG) return launch_key_switch_inst<NR1, MG>(lv1, ks_packed, out, n_gates, n1, nlv1, T, bb, stream)
     if (bb == 1) { if (T % 5 == 0) KS_GO(1, 5); if (T % 4 == 0) KS_GO(1, 4); KS_GO(1, 1); }

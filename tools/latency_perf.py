@@ -15,7 +15,7 @@ ks = rs.randint(0, 2**32, size=p.ks_shape(), dtype=np.uint64).astype(np.uint32)
 for form in ("latency", "throughput"):
     ctx = tfhe_amd.Context(p, bk, ks, form=form)
     ctx.enable_timing(True)
-    for G in (1, 32, 64, 128, 256, 512, 1024, 2048):
+    for G in (1, 4, 16, 32, 64, 128, 256, 512, 1024, 2048):
         a = torch.randint(-2**31, 2**31 - 1, (G, p.n1), dtype=torch.int32, device="cuda")
         b = torch.randint(-2**31, 2**31 - 1, (G, p.n1), dtype=torch.int32, device="cuda")
         out = torch.empty_like(a)
