@@ -364,8 +364,8 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
 //            with half h of key row r (partial products to LDS);
 //   phase 2: wave (col, h) sums the partial products of half h of column col and
 //            inverse-transforms them up to the last stage;
-//   phase 3: the last stage pairs the two halves through LDS; wave (col, h) finishes positions
-//            256 h .. 256 h + 255 and updates the accumulator.
+//   phase 3: the last stage pairs the two halves through LDS and updates the accumulator, two
+//            registers of one half column per wave (all twelve waves).
 // Against one wave per gate (blind_rotate_512_kernel) the dependent chain of a step is one half
 // forward transform, one multiply and one half inverse transform instead of six, eighteen and
 // three whole ones, and all four SIMDs carry the same load in phase 1 (a variant with one wave per
@@ -462,7 +462,14 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
         __syncthreads();
 
         // ---- phase 2: half h of column r (waves with r <= K) ----
-        uint32_t acc_old[4];
+        // Phase 3 is spread over all waves: wave (r, h) finishes registers 2 p3, 2 p3 + 1 of half h of
+        // column c3, where (c3, p3) = (r, 0) for the waves that ran phase 2 and (r - (K+1), 1) for
+        // the others.  The accumulator words a wave will update (nobody else writes them) are fetched
+        // here so that phase 3 has one LDS round trip less.
+        const int c3 = r < K1 ? r : r - K1, p3 = r < K1 ? 0 : 1;
+        uint32_t acc_old[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) acc_old[k] = s_acc[c3][256 * h + 64 * (2 * p3 + k) + lane];
         if (r < K1) {
             double sum[4];
 #pragma unroll
@@ -480,21 +487,17 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
             half_inverse(sum, h, u, s_tw + 3 * kHalfRows, tr, lane);  // |sum| <= 2 p
 #pragma unroll
             for (int k = 0; k < 4; k++) s_x[r][256 * h + 64 * k + lane] = sum[k];
-            // the accumulator words this wave will update (nobody else writes them): fetched
-            // here so that phase 3 has one LDS round trip less
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc_old[k] = s_acc[r][256 * h + 64 * k + lane];
         }
         __syncthreads();
 
         // ---- phase 3: last stage (distance 256, twiddle index 1) and accumulator update ----
-        if (r < K1) {
+        static_assert(R == 2 * K1, "phase 3 gives every wave two registers of one half column");
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const double a = s_x[r][64 * k + lane], b = s_x[r][256 + 64 * k + lane];
-                const double v = h ? mulmod_tw(a - b, u.iw[1], u.iwp[1], p) : a + b;
-                s_acc[r][256 * h + 64 * k + lane] = acc_old[k] + to_torus(v, p, pinv);
-            }
+        for (int k = 0; k < 2; k++) {
+            const int j = 64 * (2 * p3 + k) + lane;
+            const double a = s_x[c3][j], b = s_x[c3][256 + j];
+            const double v = h ? mulmod_tw(a - b, u.iw[1], u.iwp[1], p) : a + b;
+            s_acc[c3][256 * h + j] = acc_old[k] + to_torus(v, p, pinv);
         }
         __syncthreads();
     }
