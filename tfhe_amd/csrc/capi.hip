@@ -518,7 +518,9 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
                 CTX_TRY(hipMemcpyAsync(up_bk.p, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
                 src = up_bk.as<uint32_t>();
             }
-            CTX_TRY(launch_replica_key(src, ctx->d_tw, ctx->d_spec, bk_words / p->N, p->N, ctx->stream));
+            // the wave-per-gate kernel reads the spectra in the order its first transform leaves them
+            const int wave_order = !ctx->replica_generic && replica_has_fast_kernel(p->N, p->K, p->L, p->bg_bit);
+            CTX_TRY(launch_replica_key(src, ctx->d_tw, ctx->d_spec, bk_words / p->N, p->N, wave_order, ctx->stream));
         } else if (ctx->fast) {
             const TwiddleSet tw = make_twiddles(p->N);
             build_uniform(ctx->u, tw);

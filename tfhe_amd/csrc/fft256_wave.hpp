@@ -157,26 +157,57 @@ __device__ __forceinline__ void fft256_wave2(Cx4& a, Cx4& b, const d2* rows, d2 
     cx_group(b, r4);
 }
 
-__device__ __forceinline__ int brev8(int v) { return (int)(__brev((unsigned)v) >> 24); }
-
-// From the transform's output order (layout 4) to natural order in layout 1: lane (l, k) ends up
-// with natural index 64 k + l, which sits at position bitrev8(64 k + l).
-__device__ __forceinline__ void cx_to_natural(Cx4& x, double* tr, int lane) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int p = 4 * lane + k, a = p + (p >> 3);
-        tr[a] = x.re[k];
-        tr[kHalfTrWords + a] = x.im[k];
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int p = brev8(64 * k + lane), a = p + (p >> 3);
-        x.re[k] = tr[a];
-        x.im[k] = tr[kHalfTrWords + a];
-    }
-    wave_lds_fence();
+// The same network run from the other end of the lane index, for a transform whose INPUT sits in
+// layout 4 with position p holding input index bitrev8(p) -- which is how fft256_wave2 leaves its
+// output, so the second transform of a product needs no permutation in between.  Stage i pairs
+// input indices that differ in bit 7 - i, i.e. positions that differ in bit i: stages 0, 1 are
+// register bits of layout 4, stages 2, 3 of layout 3, 4, 5 of layout 2, 6, 7 of layout 1, the low
+// register bit first.  A lane's block at the first stage of group g is the reversal of the low
+// 2 (g - 1) bits of its position.  In place, the output with index o ends at input index
+// bitrev8(o), i.e. at position o: the result is in natural order in layout 1 (position 64 k + lane).
+__device__ __forceinline__ void cx_group_rev(Cx4& x, const d2* row) {
+    const d2 w0 = row[0], w1 = row[1], w2 = row[2];
+    cx_butterfly2(x.re[0], x.im[0], x.re[1], x.im[1], w0, x.re[2], x.im[2], x.re[3], x.im[3], w0);
+    cx_butterfly2(x.re[0], x.im[0], x.re[2], x.im[2], w1, x.re[1], x.im[1], x.re[3], x.im[3], w2);
 }
+
+__device__ __forceinline__ void cx_group_first_rev(Cx4& x, d2 w23) {
+    double s, d;
+#define TFHE_AMD_ADDSUB(a, b) s = a + b; d = a - b; a = s; b = d;
+    TFHE_AMD_ADDSUB(x.re[0], x.re[1]) TFHE_AMD_ADDSUB(x.im[0], x.im[1])
+    TFHE_AMD_ADDSUB(x.re[2], x.re[3]) TFHE_AMD_ADDSUB(x.im[2], x.im[3])
+    TFHE_AMD_ADDSUB(x.re[0], x.re[2]) TFHE_AMD_ADDSUB(x.im[0], x.im[2])
+#undef TFHE_AMD_ADDSUB
+    cx_butterfly(x.re[1], x.im[1], x.re[3], x.im[3], w23);
+}
+
+__device__ __forceinline__ void fft256_wave2_rev(Cx4& a, Cx4& b, const d2* rows, d2 w23, double* tra, double* trb, int lane) {
+    const int u2 = (int)(__brev((unsigned)lane & 3u) >> 30);
+    const int u3 = (int)(__brev((unsigned)lane & 15u) >> 28);
+    const int u4 = (int)(__brev((unsigned)lane) >> 26);
+    const d2* p2 = rows + 3 * (fft_row_offset(2) + u2);
+    const d2* p3 = rows + 3 * (fft_row_offset(3) + u3);
+    const d2* p4 = rows + 3 * (fft_row_offset(4) + u4);
+    cx_group_first_rev(a, w23);
+    cx_transpose<4, 3>(a, tra, lane);
+    const d2 r2[3] = {p2[0], p2[1], p2[2]};
+    cx_group_first_rev(b, w23);
+    cx_transpose<4, 3>(b, trb, lane);
+    cx_group_rev(a, r2);
+    cx_transpose<3, 2>(a, tra, lane);
+    const d2 r3[3] = {p3[0], p3[1], p3[2]};
+    cx_group_rev(b, r2);
+    cx_transpose<3, 2>(b, trb, lane);
+    cx_group_rev(a, r3);
+    cx_transpose_1_2(a);  // its own inverse: layout 2 -> layout 1
+    const d2 r4[3] = {p4[0], p4[1], p4[2]};
+    cx_group_rev(b, r3);
+    cx_transpose_1_2(b);
+    cx_group_rev(a, r4);
+    cx_group_rev(b, r4);
+}
+
+__device__ __forceinline__ int brev8(int v) { return (int)(__brev((unsigned)v) >> 24); }
 
 // reference src/types.hpp:28-33 for a finite d: fmod(d, 1), plus 1 if negative, times 2^32,
 // truncated through 64 bits (a value that rounds up to exactly 2^32 wraps to 0).  d - floor(d) is

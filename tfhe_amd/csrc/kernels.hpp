@@ -28,7 +28,8 @@ hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* 
 // blind rotation through a replay of the reference's FFT product (replica_kernels.hip); tables: [4][N/2]
 // complex (twist, omega, untwist, reversed omega powers); spec: [polys][N/2] complex key spectra
 bool replica_has_kernel(int N, int K, int L);
-hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, size_t n_polys, int N, hipStream_t stream);
+hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, size_t n_polys, int N, int wave_order,
+                              hipStream_t stream);
 // generic != 0: the one-workgroup-per-gate kernel even where the wave-per-gate one exists (cross-checking)
 bool replica_has_fast_kernel(int N, int K, int L, int bg);
 hipError_t launch_blind_rotate_replica(const d2* spec, const d2* tables, const uint32_t* c, const uint32_t* tv,

@@ -78,9 +78,11 @@ struct RepShape {
 
 // Tables: [4][M] complex = twist powers, forward omega powers, untwist powers, reversed omega powers.
 // Key spectra: for every key polynomial, fft(twist(fold(poly / 2^32))) / M in natural order, [M] complex.
+// wave_order != 0 (N = 512 only): entry 64 k + lane holds the spectrum value of index
+// bitrev8(4 lane + k), the order in which the wave-per-gate kernel's first transform leaves its output.
 __global__ void __launch_bounds__(kRepThreads)
 replica_key_kernel(const uint32_t* __restrict__ bk, const d2* __restrict__ tables, d2* __restrict__ spec, int N,
-                   int bits) {
+                   int bits, int wave_order) {
     extern __shared__ d2 s_rep[];
     const int M = N >> 1;
     d2* s_omega = s_rep;      // [M]
@@ -99,7 +101,9 @@ replica_key_kernel(const uint32_t* __restrict__ bk, const d2* __restrict__ table
     // exactly with every rounding in between: the factor is applied here, once per key.
     const double scale = 1.0 / M;
     for (int i = threadIdx.x; i < M; i += kRepThreads) {
-        d2 v = buf[bitrev(i, bits)];
+        // natural index i sits at buf[bitrev(i)]; in wave order entry i = 64 k + lane wants natural
+        // index bitrev8(4 lane + k), which sits at buf[4 lane + k]
+        d2 v = wave_order ? buf[4 * (i & 63) + (i >> 6)] : buf[bitrev(i, bits)];
         v.x *= scale;
         v.y *= scale;
         spec[poly * M + i] = v;
@@ -199,9 +203,10 @@ blind_rotate_replica_kernel(const d2* __restrict__ spec, const d2* __restrict__ 
 // 256-point transforms evaluated in registers (fft256_wave.hpp), same structure as
 // blind_rotate_512_kernel.  Per step and accumulator polynomial q the two digit polynomials
 // (levels 0 and 1) run as one interleaved pair of transforms: fold and twist, forward transforms,
-// permutation to natural order, then per column: pointwise products with the two key spectra (which
-// carry the 1/M factor), the pair of second transforms, untwist, truncating conversion of both
-// parts, wrap-around sum.  The reference rounds every product on its own, so there are
+// then per column: pointwise products with the two key spectra (stored in the order the forward
+// transform leaves its output, and carrying the 1/M factor), the pair of second transforms (run
+// from that order, so nothing is permuted in between, and ending in natural order), untwist,
+// truncating conversion of both parts, wrap-around sum.  The reference rounds every product on its own, so there are
 // (K+1) L (K+1) = 18 second transforms per step where the exact path needs K + 1 = 3 inverse NTTs.
 // Pairing hides the LDS latency of one transform's transposition behind the other's butterflies;
 // the first transposition of every transform stays in registers (half-wave and row swaps).
@@ -215,12 +220,12 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
     static_assert(L == 2, "the two levels of a digit polynomial run as one interleaved pair of transforms");
     constexpr int K1 = K + 1, R = K1 * L, BG = 8, M = 256;
     __shared__ d2 s_rows[2 * kFftRows * 3];
-    __shared__ d2 s_untwist[M];  // entry 64 k + lane: the power for position 4 lane + k, natural index bitrev8(4 lane + k)
+    __shared__ d2 s_untwist[M];  // natural order
     __shared__ double s_tr[4][2][2 * kHalfTrWords];
     __shared__ uint32_t s_acc[4][K1][kN];
 
     for (int i = threadIdx.x; i < 2 * kFftRows * 3; i += 256) s_rows[i] = tables[4 * M + i];
-    for (int i = threadIdx.x; i < M; i += 256) s_untwist[i] = tables[4 * M + kFftUntwistPos + 4 * (i & 63) + (i >> 6)];
+    for (int i = threadIdx.x; i < M; i += 256) s_untwist[i] = tables[2 * M + i];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -253,12 +258,8 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
         offset += 1u << (32 - BG * (l + 1) + BG - 1);
         flip |= 1u << (32 - BG * (l + 1) + BG - 1);
     }
-    int nat[4];  // natural index of position 4 lane + k
-#pragma unroll
-    for (int k = 0; k < 4; k++) nat[k] = brev8(4 * lane + k);
     const d2 w23_fwd = rows_fwd[2], w23_inv = rows_inv[2];
     const d2* row2_fwd = rows_fwd + 3 * (fft_row_offset(2) + fft_row<2>(lane));
-    const d2* row2_inv = rows_inv + 3 * (fft_row_offset(2) + fft_row<2>(lane));
     const d2* twist = tables + lane;  // powers for the points 64 k + lane
 
     uint32_t cvals = 0;
@@ -310,8 +311,6 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                 x1.im[k] = ad1 + bc1;
             }
             fft256_wave2(x0, x1, rows_fwd, w23_fwd, row2_fwd, tr0, tr1, lane);
-            cx_to_natural(x0, tr0, lane);
-            cx_to_natural(x1, tr1, lane);
 #pragma unroll
             for (int col = 0; col < K1; col++) {
                 Cx4 p0, p1;
@@ -333,7 +332,7 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                         y1[k] = key1[(col + 1) * M + 64 * k + lane];
                     }
                 }
-                fft256_wave2(p0, p1, rows_inv, w23_inv, row2_inv, tr0, tr1, lane);
+                fft256_wave2_rev(p0, p1, rows_inv, w23_inv, tr0, tr1, lane);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const d2 u = s_untwist[64 * k + lane];
@@ -351,8 +350,8 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
         for (int col = 0; col < K1; col++)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                acc[col][nat[k]] += lo[col][k];
-                acc[col][nat[k] + M] += hi[col][k];
+                acc[col][64 * k + lane] += lo[col][k];
+                acc[col][64 * k + lane + M] += hi[col][k];
             }
         wave_lds_fence();
     }
@@ -389,12 +388,14 @@ bool replica_has_kernel(int N, int K, int L) {
     return replica_lds_bytes(N, K + 1, (K + 1) * L) <= 160 * 1024;
 }
 
-hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, size_t n_polys, int N, hipStream_t stream) {
+hipError_t launch_replica_key(const uint32_t* bk, const d2* tables, d2* spec, size_t n_polys, int N, int wave_order,
+                              hipStream_t stream) {
     if (n_polys == 0) return hipSuccess;
     int bits = 0;
     while ((1 << bits) < N / 2) bits++;
     const size_t lds = sizeof(d2) * (size_t)N;  // 2 M
-    replica_key_kernel<<<(unsigned)n_polys, kRepThreads, lds, stream>>>(bk, tables, spec, N, bits);
+    if (wave_order && N != 512) return hipErrorInvalidValue;
+    replica_key_kernel<<<(unsigned)n_polys, kRepThreads, lds, stream>>>(bk, tables, spec, N, bits, wave_order);
     return hipGetLastError();
 }
 
