@@ -204,8 +204,7 @@ std::vector<double> build_replica_tables(int N) {
         t[((size_t)3 * M + i) * 2 + 1] = t[((size_t)1 * M + src) * 2 + 1];
     }
     if (M == 256) {
-        // block of the wave-per-gate kernel (fft256_wave.hpp): per-lane twiddle rows of both
-        // directions, then the untwist powers in the transform's output (position) order
+        // block of the wave-per-gate kernel (fft256_wave.hpp): per-lane twiddle rows of both directions
         t.resize((size_t)(4 * M + kFftFastPairs) * 2);
         auto copy = [&](size_t dst_pair, size_t src_pair) {
             t[dst_pair * 2] = t[src_pair * 2];
@@ -222,7 +221,6 @@ std::vector<double> build_replica_tables(int N) {
                     copy(row + 2, tab + bit_reverse(4 * U + 2, 8));
                 }
         }
-        for (int m = 0; m < M; m++) copy(base + kFftUntwistPos + m, (size_t)2 * M + bit_reverse(m, 8));
     }
     return t;
 }

@@ -26,9 +26,9 @@ struct Cx4 {
 constexpr int kFftRows = 1 + 4 + 16 + 64;  // rows per direction
 __host__ __device__ constexpr int fft_row_offset(int g) { return g == 1 ? 0 : (g == 2 ? 1 : (g == 3 ? 5 : 21)); }
 // table block appended to the [4][256] base tables of the replica mode, in complex (d2) units:
-//   forward rows [85][3] | reversed-omega rows [85][3] | untwist powers permuted to position order [256]
-constexpr int kFftFwdRows = 0, kFftInvRows = kFftRows * 3, kFftUntwistPos = 2 * kFftRows * 3;
-constexpr int kFftFastPairs = 2 * kFftRows * 3 + 256;
+//   forward rows [85][3] | reversed-omega rows [85][3]
+constexpr int kFftFwdRows = 0, kFftInvRows = kFftRows * 3;
+constexpr int kFftFastPairs = 2 * kFftRows * 3;
 
 template <int G>
 __device__ __forceinline__ int fft_row(int lane) {

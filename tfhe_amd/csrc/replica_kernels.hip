@@ -258,7 +258,14 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
         offset += 1u << (32 - BG * (l + 1) + BG - 1);
         flip |= 1u << (32 - BG * (l + 1) + BG - 1);
     }
-    const d2 w23_fwd = rows_fwd[2], w23_inv = rows_inv[2];
+    // wave-uniform twiddles of the second stage: kept in scalar registers
+    auto uniform = [](double v) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                                __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    };
+    d2 w23_fwd = rows_fwd[2], w23_inv = rows_inv[2];
+    w23_fwd.x = uniform(w23_fwd.x); w23_fwd.y = uniform(w23_fwd.y);
+    w23_inv.x = uniform(w23_inv.x); w23_inv.y = uniform(w23_inv.y);
     const d2* row2_fwd = rows_fwd + 3 * (fft_row_offset(2) + fft_row<2>(lane));
     const d2* twist = tables + lane;  // powers for the points 64 k + lane
 
