@@ -85,21 +85,8 @@ __device__ __forceinline__ void cx_group_first(Cx4& x, d2 w23) {
     cx_butterfly(x.re[2], x.im[2], x.re[3], x.im[3], w23);
 }
 
-// Layout 1 -> layout 2 without the LDS: the element of lane L, point K goes to lane 16 K + (L & 15),
-// point L >> 4, a 4 x 4 transposition between the two point bits and lane bits 5 and 4, which the
-// half-wave and row swaps of gfx950 do in place (one instruction per 32-bit register pair).
-__device__ __forceinline__ void swap_half_waves(double& a, double& b) {  // a's lanes 32..63 <-> b's lanes 0..31
-    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)hi[0], (int)lo[0]);
-    b = __hiloint2double((int)hi[1], (int)lo[1]);
-}
-__device__ __forceinline__ void swap_rows(double& a, double& b) {  // a's odd 16-lane rows <-> b's even rows
-    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)hi[0], (int)lo[0]);
-    b = __hiloint2double((int)hi[1], (int)lo[1]);
-}
+// Layout 1 <-> layout 2 without the LDS (swap_half_waves, swap_rows: ntt512_half.hpp), real and
+// imaginary parts alike.
 __device__ __forceinline__ void cx_transpose_1_2(Cx4& x) {
     swap_half_waves(x.re[0], x.re[2]); swap_half_waves(x.im[0], x.im[2]);
     swap_half_waves(x.re[1], x.re[3]); swap_half_waves(x.im[1], x.im[3]);

@@ -2,7 +2,8 @@
 // blind rotation: after the first radix-2 stage (distance 256) the two halves of the vector are
 // independent length-256 transforms, so wave h in {0, 1} computes stage 0 for its own half from
 // the (cheap, 8-bit) inputs and then owns positions 256 h .. 256 h + 255: 4 coefficients per lane,
-// four groups of two radix-2 stages in registers, three transposes through a private LDS buffer.
+// four groups of two radix-2 stages in registers, two transposes through a private LDS buffer and
+// one in registers.
 // Same field, same modular arithmetic, same spectrum order as ntt512.hpp: the half-h wave ends
 // with spectrum positions 256 h + 4 lane + k, which in the full transform's layout C
 // (position 8 l + k) are lane l = 32 h + (lane >> 1), registers 4 (lane & 1) + k.
@@ -77,6 +78,29 @@ __device__ __forceinline__ void half_transpose(double (&x)[4], double* tr, int l
     wave_lds_fence();
 }
 
+// Layout 1 <-> layout 2 without the LDS: the element of lane L, register K goes to lane
+// 16 K + (L & 15), register L >> 4, a 4 x 4 transposition between the two register bits and lane
+// bits 5 and 4, which the half-wave and row swaps of gfx950 do in place (one instruction per 32-bit
+// register pair).  The transposition is its own inverse.
+__device__ __forceinline__ void swap_half_waves(double& a, double& b) {  // a's lanes 32..63 <-> b's lanes 0..31
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap_rows(double& a, double& b) {  // a's odd 16-lane rows <-> b's even rows
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void half_transpose_1_2(double (&x)[4]) {
+    swap_half_waves(x[0], x[2]);
+    swap_half_waves(x[1], x[3]);
+    swap_rows(x[0], x[1]);
+    swap_rows(x[2], x[3]);
+}
+
 // two Cooley-Tukey stages on 4 registers: pairs (0,2), (1,3), then (0,1), (2,3)
 template <bool REDUCE_A>
 __device__ __forceinline__ void ct4(double (&x)[4], const Tw3& t, double p, double pinv) {
@@ -124,7 +148,7 @@ __device__ __forceinline__ void half_forward_small(double (&x)[4], const double 
     bf_ct(x[0], x[1], t.w[1], t.wp[1], p);
     bf_ct(x[2], x[3], t.w[2], t.wp[2], p);
 
-    half_transpose<1, 2>(x, tr, lane);
+    half_transpose_1_2(x);
     load_tw3(t, s_tw + 3 * (half_row_offset(2) + half_row<2>(h, lane)));
     ct4<false>(x, t, p, pinv);
 
@@ -162,7 +186,7 @@ __device__ __forceinline__ void half_inverse(double (&x)[4], int h, const NttUni
     gs4_near(x, t, p);
     gs4_far(x, t, p);
 
-    half_transpose<2, 1>(x, tr, lane);
+    half_transpose_1_2(x);
 #pragma unroll
     for (int k = 0; k < 4; k++) x[k] = reduce(x[k], p, pinv);
     load_tw3(t, s_tw_inv + 3 * (half_row_offset(1) + half_row<1>(h, lane)));
