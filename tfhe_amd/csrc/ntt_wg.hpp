@@ -1,7 +1,9 @@
 // Workgroup-cooperative exact negacyclic NTT of length N = 2^LOGN (N >= 1024) over the same
 // prime field and with the same FP64 modular arithmetic as ntt512.hpp.  N/8 threads transform
 // one polynomial: 8 coefficients per thread, groups of up to three radix-2 stages in registers,
-// a transpose through LDS (one block barrier each, two alternating buffers) between groups.
+// a transpose through LDS between groups: with a block barrier and two alternating buffers where
+// data crosses waves (the first transpose of a forward transform, the last of an inverse one),
+// through a wave-private buffer with no barrier where it does not.
 //
 // Stage s (distance N / 2^(s+1)) pairs positions that differ in bit beta = LOGN-1-s.  Group g
 // covers stages 3g .. 3g+2; its register layout keeps bits b+2..b of the position in the
@@ -25,6 +27,12 @@ struct WgNtt {
     static constexpr int GROUPS = (LOGN + 2) / 3;
     static constexpr int LAST = LOGN - 3 * (GROUPS - 1);  // stages in the last group: 1, 2 or 3
     static constexpr int PAD = N + N / 8;            // transpose buffer, one pad slot per 8 positions
+    // A transpose between two layouts whose bases are both <= 6 moves data only inside a wave: the
+    // thread bits from 6 up are position bits from 9 up in both, so wave v holds positions
+    // [512 v, 512 v + 512) before and after.  Such a transpose goes through the wave's own buffer
+    // and needs no block barrier.
+    static constexpr int WAVE_PAD = 512 + 512 / 8;
+    static constexpr int BUF_DOUBLES = 2 * PAD + (T / 64) * WAVE_PAD;  // two block buffers, one buffer per wave
 
     __host__ __device__ static constexpr int base(int g) { return (g == GROUPS - 1) ? 0 : LOGN - 3 * (g + 1); }
     __host__ __device__ static constexpr int stages(int g) { return (g == GROUPS - 1) ? LAST : 3; }
@@ -52,8 +60,21 @@ struct WgNtt {
         return v;
     }
 
-    // registers in layout `from` -> registers in layout `to`
-    __device__ static __forceinline__ void transpose(double (&x)[8], double* buf, int from, int to, int t) {
+    // registers in layout `from` -> registers in layout `to`.  bufs: BUF_DOUBLES doubles; `parity`
+    // selects the block buffer and is advanced once per block-level transpose.
+    __device__ static __forceinline__ void transpose(double (&x)[8], double* bufs, int& parity, int from, int to, int t) {
+        if (base(from) <= 6 && base(to) <= 6) {
+            double* wb = bufs + 2 * PAD + (t >> 6) * WAVE_PAD;
+#pragma unroll
+            for (int k = 0; k < 8; k++) wb[pad_pos(position(from, t, k) & 511)] = x[k];
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = wb[pad_pos(position(to, t, k) & 511)];
+            wave_lds_fence();
+            return;
+        }
+        double* buf = bufs + (parity & 1) * PAD;
+        parity++;
 #pragma unroll
         for (int k = 0; k < 8; k++) buf[pad_pos(position(from, t, k))] = x[k];
         __syncthreads();
@@ -106,7 +127,6 @@ struct WgNtt {
     // Out: last group's layout (position 8t + k, bit-reversed spectrum order), |x| <= 3.2 p.
     // Additive inputs are reduced at the first stage of groups >= 2 (SMALL) or >= 1; the bound
     // then stays below 4.2 p at every stage for LOGN <= 12.
-    // `parity` selects the transpose buffer and is advanced once per transpose.
     template <bool SMALL>
     __device__ static __forceinline__ void forward(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
                                                    double* bufs, int& parity, int t) {
@@ -144,8 +164,7 @@ struct WgNtt {
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
             load_tw7(tw, table + 7 * (row_offset(g) + opaque(t >> base(g))));
-            transpose(x, bufs + (parity & 1) * PAD, g - 1, g, t);
-            parity++;
+            transpose(x, bufs, parity, g - 1, g, t);
             constexpr bool kAlways = !SMALL;
             if (g == GROUPS - 1) {
                 ct_group<LAST, true>(x, tw, p, pinv);
@@ -172,8 +191,7 @@ struct WgNtt {
             for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
             if (g == GROUPS - 1) gs_group<LAST>(x, tw, p);
             else                 gs_group<3>(x, tw, p);
-            transpose(x, bufs + (parity & 1) * PAD, g, g - 1, t);
-            parity++;
+            transpose(x, bufs, parity, g, g - 1, t);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);

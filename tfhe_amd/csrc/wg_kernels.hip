@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(WgNtt<LOGN>::T)
 bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const uint32_t* __restrict__ bk,
                        d2* __restrict__ bk_ntt, int parts, int shift) {
     using W = WgNtt<LOGN>;
-    __shared__ double s_tr[2 * W::PAD];
+    __shared__ double s_tr[W::BUF_DOUBLES];
     const int t = threadIdx.x;
     const size_t poly = blockIdx.x / parts;
     const int part = blockIdx.x % parts;
@@ -52,7 +52,7 @@ bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const u
 }
 
 // Transformed key layout: [n][R][K1][parts] polynomials (part innermost), each [4][T][2] doubles.
-// Two workgroups per CU (<= 256 registers per lane, 52 KB of LDS each): while one waits at a
+// Two workgroups per CU (<= 256 registers per lane, 71 KB of LDS each): while one waits at a
 // transpose barrier the other one computes.  Measured alternatives: one workgroup per CU with
 // the L digit transforms of a polynomial interleaved in each wave (more parallelism per wave,
 // fewer barriers) is 20 % slower, three workgroups per CU spill and are 35 % slower.
@@ -63,7 +63,7 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                        int n, int shift, int extract) {
     using W = WgNtt<LOGN>;
     constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L, BG = 8;
-    __shared__ double s_tr[2 * W::PAD];
+    __shared__ double s_tr[W::BUF_DOUBLES];
     __shared__ uint32_t s_acc[K1][N];
     const int t = threadIdx.x;
     const size_t gate = blockIdx.x;
