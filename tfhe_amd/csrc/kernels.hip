@@ -703,9 +703,9 @@ key_switch_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__
 constexpr int kKsSmallThreads = 320;
 constexpr int kKsSmallMaxSlice = 64;  // lv1 coefficients per workgroup at most
 #ifndef TFHE_AMD_KS_SMALL_MAX_GATES
-#define TFHE_AMD_KS_SMALL_MAX_GATES 64
+#define TFHE_AMD_KS_SMALL_MAX_GATES 16
 #endif
-// larger batches take the tiled kernel (measured: 0.10 against 0.13 ms at 64 gates, 0.18 against 0.14 ms at 128)
+// larger batches take the tiled kernel (measured: 0.03 against 0.04 ms at 16 gates, 0.06 against 0.05 ms at 32)
 constexpr int kKsSmallMaxGates = TFHE_AMD_KS_SMALL_MAX_GATES;
 
 template <int T, int BB>
@@ -820,9 +820,10 @@ static hipError_t launch_key_switch_inst(const uint32_t* lv1, const uint32_t* ks
     if (e != hipSuccess) return e;
     const int rowp = key_switch_row_words(n1);
     const int tiles = (n_gates + kKsTile - 1) / kKsTile, slabs = rowp / kKsSlab;
-    // slices of the lv1 range: aim at two workgroups per CU, never finer than one digit chunk
+    // slices of the lv1 range: aim at two workgroups per CU, never finer than 16 coefficients
+    // (every slice adds one atomic per output word and gate)
     int parts = 1;
-    while (tiles * slabs * parts * 2 <= 512 && parts * 2 * kKsChunk <= nlv1) parts *= 2;
+    while (tiles * slabs * parts * 2 <= 512 && parts * 2 * 16 <= nlv1) parts *= 2;
     if (parts > 1) {
         e = hipMemsetAsync(out, 0, (size_t)n_gates * n1 * sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
