@@ -65,20 +65,21 @@ def test_stages_bit_exact(keys, ctx, octx):
     assert np.array_equal(dout.cpu().numpy().view(np.uint32), want_out)
 
 
-def test_key_switch_random_lv1(keys, ctx):
-    """identity_key_switch on uniformly random lv1 words (every digit pattern, ragged tile)."""
+@pytest.mark.parametrize("rows", [1, 4, 16, 17, 37, 130])
+def test_key_switch_random_lv1(keys, ctx, rows):
+    """identity_key_switch on uniformly random lv1 words (every digit pattern, ragged tile), at
+    batch sizes on both sides of the switch between the per-gate kernel and the tiled one."""
     import torch
 
     p, _, _, _, ks = keys
-    rs = np.random.RandomState(5)
-    lv1 = rs.randint(0, 2**32, size=(37, p.lv1 + 1), dtype=np.uint64).astype(np.uint32)
-    lv1[0, 1:] = 0
-    lv1[1, 1:] = 0xFFFFFFFF
-    lv1[2, 1:] = 0x001FFFFF  # just below the rounding boundary
-    lv1[3, 1:] = 0x00200000
+    rs = np.random.RandomState(5 + rows)
+    lv1 = rs.randint(0, 2**32, size=(rows, p.lv1 + 1), dtype=np.uint64).astype(np.uint32)
+    for i, word in enumerate((0, 0xFFFFFFFF, 0x001FFFFF, 0x00200000)):  # 0x001FFFFF: just below the rounding boundary
+        if i < rows:
+            lv1[i, 1:] = word
     want = np.stack([O.identity_key_switch(l, ks, p) for l in lv1])
     dlv1 = torch.from_numpy(lv1.view(np.int32)).cuda()
-    dout = torch.empty((37, p.n + 1), dtype=torch.int32, device="cuda")
+    dout = torch.empty((rows, p.n + 1), dtype=torch.int32, device="cuda")
     ctx.identity_key_switch_device(dlv1, dout)
     ctx.synchronize()
     assert np.array_equal(dout.cpu().numpy().view(np.uint32), want)
