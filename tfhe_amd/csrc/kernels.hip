@@ -317,11 +317,14 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
 #if TFHE_AMD_PAIR_THROUGHPUT
         static_assert(K1 == 3, "inverse transforms run as one pair and one single");
         ntt512_inverse2(out[0], out[1], u, s_tw, tr, tr2, lane);
-        ntt512_inverse<true>(out[2], u, s_tw, tr, lane);
-#pragma unroll
-        for (int col = 0; col < K1; col++)
+        // the accumulator updates of the first two columns run while the third transform's
+        // transpositions are in flight
+        auto update = [&](int col) {
 #pragma unroll
             for (int k = 0; k < 8; k++) acc[col][64 * k + lane] += to_torus(out[col][k], p, pinv);
+        };
+        ntt512_inverse_overlapped(out[2], u, s_tw, tr, lane, [&]() { update(0); }, [&]() { update(1); });
+        update(2);
 #else
 #pragma unroll
         for (int col = 0; col < K1; col++) {

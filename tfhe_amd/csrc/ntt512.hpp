@@ -479,6 +479,28 @@ __device__ __forceinline__ void ntt512_inverse2(double (&a)[8], double (&b)[8], 
     gs8_pinned(b, u.iw + 1, u.iwp + 1, p);
 }
 
+// ntt512_inverse<true> with two pieces of the caller's independent work placed where a
+// transposition's loads are in flight (after1 behind the first transposition, after2 behind the
+// second), so that a lone transform does not sit out the exchange latency.
+template <typename A1, typename A2>
+__device__ __forceinline__ void ntt512_inverse_overlapped(double (&x)[8], const NttUniform& u, const d2* s_tw, double* tr,
+                                                          int lane, A1 after1, A2 after2) {
+    const double p = u.p, pinv = u.pinv;
+    Tw7 t;
+    reduce_n<8>(x, p, pinv);
+    load_tw7(t, s_tw + kTwInvC + 7 * lane);
+    gs8_pinned(x, t.w, t.wp, p);
+    transpose_c_to_b(x, tr, lane);
+    load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
+    after1();
+    reduce_n<8>(x, p, pinv);
+    gs8_pinned(x, t.w, t.wp, p);
+    transpose_b_to_a(x, tr, lane);
+    after2();
+    reduce_n<8>(x, p, pinv);
+    gs8_pinned(x, u.iw + 1, u.iwp + 1, p);
+}
+
 // Inverse transform without the 1/N factor.  In: layout C, |x| < 2^53.  Out: layout A,
 // |x| <= 4 p.  Every group of three GS stages starts from |x| <= p/2 and doubles the bound
 // of the sum outputs at most three times.
