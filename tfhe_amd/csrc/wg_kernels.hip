@@ -1,5 +1,6 @@
-// Blind rotation for ring degrees N >= 1024 (the N = 2048 stress set): one workgroup of N/8
-// threads owns one gate and transforms every polynomial cooperatively (ntt_wg.hpp).
+// Blind rotation for ring degrees N >= 1024 (the N = 2048 stress set, and N = 1024 with K = 1):
+// one workgroup of N/8 threads owns one gate and transforms every polynomial cooperatively
+// (ntt_wg.hpp).
 //
 // The field's prime (p/2 = 2^49.6) is smaller than the largest negacyclic accumulation of these
 // sets ((K+1) L N 2^7 2^31 = 2^51.6 for N = 2048, K = 1, L = 3), so the bootstrapping key is split
@@ -194,9 +195,13 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
 
 // ---- host side ---------------------------------------------------------------------------------
 
-bool wg_has_kernel(int N, int K, int L, int bg) { return bg == 8 && N == 2048 && K == 1 && L == 3; }
+// parameter sets with an instantiation: the N = 2048 stress set, and N = 1024 with K = 1, L = 2 or 3
+bool wg_has_kernel(int N, int K, int L, int bg) {
+    if (bg != 8 || K != 1) return false;
+    return (N == 2048 && L == 3) || (N == 1024 && (L == 2 || L == 3));
+}
 
-int wg_table_pairs(int N) { return N == 2048 ? WgNtt<11>::TABLE_PAIRS : 0; }
+int wg_table_pairs(int N) { return N == 2048 ? WgNtt<11>::TABLE_PAIRS : N == 1024 ? WgNtt<10>::TABLE_PAIRS : 0; }
 
 // number of key parts and the split position for a parameter set: one part if the largest
 // accumulation (K+1) L N 2^(bg-1) 2^31 stays below p/2 with margin, else two halves of 16 bits
@@ -208,9 +213,15 @@ void wg_split(int N, int K, int L, int bg, int* parts, int* shift) {
 
 hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_polys,
                                   int N, int parts, int shift, hipStream_t stream) {
-    if (N != 2048) return hipErrorInvalidValue;
-    bk_transform_wg_kernel<11><<<(unsigned)(n_polys * parts), WgNtt<11>::T, 0, stream>>>(u, table, bk, bk_ntt, parts,
-                                                                                         shift);
+    if (n_polys == 0) return hipSuccess;
+    if (N == 2048)
+        bk_transform_wg_kernel<11><<<(unsigned)(n_polys * parts), WgNtt<11>::T, 0, stream>>>(u, table, bk, bk_ntt, parts,
+                                                                                             shift);
+    else if (N == 1024)
+        bk_transform_wg_kernel<10><<<(unsigned)(n_polys * parts), WgNtt<10>::T, 0, stream>>>(u, table, bk, bk_ntt, parts,
+                                                                                             shift);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -218,9 +229,14 @@ hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2
                                   const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L,
                                   int parts, int shift, int extract, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
-    if (!(N == 2048 && K == 1 && L == 3 && parts == 2)) return hipErrorInvalidValue;
-    blind_rotate_wg_kernel<11, 1, 3, 2><<<(unsigned)n_gates, WgNtt<11>::T, 0, stream>>>(u, table, bk_ntt, c, tv, out, n,
-                                                                                         shift, extract);
+    if (!wg_has_kernel(N, K, L, 8) || parts != 2) return hipErrorInvalidValue;
+#define WG_GO(LOGN, KK, LL)                                                                                          \
+    blind_rotate_wg_kernel<LOGN, KK, LL, 2><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, \
+                                                                                              out, n, shift, extract)
+    if (N == 2048) WG_GO(11, 1, 3);
+    else if (L == 3) WG_GO(10, 1, 3);
+    else WG_GO(10, 1, 2);
+#undef WG_GO
     return hipGetLastError();
 }
 
