@@ -170,23 +170,23 @@ def test_n2048_ntt_path_vs_generic_and_oracle():
             assert np.array_equal(fast.gate_bootstrapping_tlwe_to_tlwe(c), gen.gate_bootstrapping_tlwe_to_tlwe(c))
 
 
-@pytest.mark.parametrize("L", [2, 3])
-def test_n1024_ntt_path_vs_generic_and_oracle(L):
-    """N = 1024 with K = 1 and L = 2 or 3: the workgroup NTT kernels (two waves per gate, split key)
-    vs the O(N^2) wrap-around kernels vs the oracle, including key words at the ends of the range,
-    and a NAND end to end on generated keys."""
+@pytest.mark.parametrize("N,K,L", [(1024, 1, 2), (1024, 1, 3), (1024, 2, 2), (1024, 2, 3), (2048, 1, 2)])
+def test_workgroup_ntt_sets_vs_generic_and_oracle(N, K, L):
+    """The other parameter sets with workgroup NTT kernels (split key; two waves per gate at
+    N = 1024) vs the O(N^2) wrap-around kernels vs the oracle, including key words at the ends of
+    the range, and a NAND end to end on generated keys."""
     import tfhe_amd
 
     n = 4
-    p = tfhe_amd.Params(n, 1024, 1, 8, L, 5, 2)
-    op = O.params_from(n, 1024, 1, 8, L, 5, 2)
-    rs = np.random.RandomState(77 + L)
+    p = tfhe_amd.Params(n, N, K, 8, L, 5, 2)
+    op = O.params_from(n, N, K, 8, L, 5, 2)
+    rs = np.random.RandomState(77 + L + N + K)
     keys = [rs.randint(0, 2**32, size=p.bk_shape(), dtype=np.uint64).astype(np.uint32),
             np.full(p.bk_shape(), 0x80000000, dtype=np.uint32),
             np.full(p.bk_shape(), 0x7FFF8000, dtype=np.uint32)]
     c = rs.randint(0, 2**32, size=(7, n + 1), dtype=np.uint64).astype(np.uint32)
-    c[0, 1:] = 0x00200000  # rotate by one position every step
-    tv = rs.randint(0, 2**32, size=(2, 1024), dtype=np.uint64).astype(np.uint32)
+    c[0, 1:] = 0x80000000 // N  # rotate by one position every step
+    tv = rs.randint(0, 2**32, size=(K + 1, N), dtype=np.uint64).astype(np.uint32)
     for bk in keys:
         with tfhe_amd.Context(p, bk, None) as fast, tfhe_amd.Context(p, bk, None, generic_kernels=True) as gen:
             assert fast.kernel_family() == "ntt-workgroup" and gen.kernel_family() == "generic"
@@ -195,8 +195,8 @@ def test_n1024_ntt_path_vs_generic_and_oracle(L):
                 assert np.array_equal(got, gen.blind_rotate(c, t))
                 assert np.array_equal(got[0], O.blind_rotate(c[0], bk, op, O.NTT, tv=t))
             assert np.array_equal(fast.gate_bootstrapping_tlwe_to_tlwe(c), gen.gate_bootstrapping_tlwe_to_tlwe(c))
-    # end to end: n = 300 keeps the oracle's key generation short
-    op = O.params_from(300, 1024, 1, 8, L, 8, 2)
+    # end to end: n = 200 keeps the oracle's key generation short
+    op = O.params_from(200, N, K, 8, L, 8, 2)
     s0, sr, bk, ks = O.keyset(op, seed=6 + L)
     p = tfhe_amd.Params(op.n, op.N, op.K, op.bg_bit, op.L, op.T, op.base_bit)
     r = O.rng(2)

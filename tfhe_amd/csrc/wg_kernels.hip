@@ -1,4 +1,4 @@
-// Blind rotation for ring degrees N >= 1024 (the N = 2048 stress set, and N = 1024 with K = 1):
+// Blind rotation for ring degrees N >= 1024 (N = 2048 with K = 1, N = 1024 with K = 1 or 2):
 // one workgroup of N/8 threads owns one gate and transforms every polynomial cooperatively
 // (ntt_wg.hpp).
 //
@@ -195,10 +195,11 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
 
 // ---- host side ---------------------------------------------------------------------------------
 
-// parameter sets with an instantiation: the N = 2048 stress set, and N = 1024 with K = 1, L = 2 or 3
+// parameter sets with an instantiation (8-bit gadget): N = 2048 with K = 1 and N = 1024 with K = 1 or
+// 2, L = 2 or 3 each
 bool wg_has_kernel(int N, int K, int L, int bg) {
-    if (bg != 8 || K != 1) return false;
-    return (N == 2048 && L == 3) || (N == 1024 && (L == 2 || L == 3));
+    if (bg != 8 || (L != 2 && L != 3)) return false;
+    return (N == 2048 && K == 1) || (N == 1024 && (K == 1 || K == 2));
 }
 
 int wg_table_pairs(int N) { return N == 2048 ? WgNtt<11>::TABLE_PAIRS : N == 1024 ? WgNtt<10>::TABLE_PAIRS : 0; }
@@ -233,9 +234,9 @@ hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2
 #define WG_GO(LOGN, KK, LL)                                                                                          \
     blind_rotate_wg_kernel<LOGN, KK, LL, 2><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, \
                                                                                               out, n, shift, extract)
-    if (N == 2048) WG_GO(11, 1, 3);
-    else if (L == 3) WG_GO(10, 1, 3);
-    else WG_GO(10, 1, 2);
+    if (N == 2048) { if (L == 3) WG_GO(11, 1, 3); else WG_GO(11, 1, 2); }
+    else if (K == 1) { if (L == 3) WG_GO(10, 1, 3); else WG_GO(10, 1, 2); }
+    else { if (L == 3) WG_GO(10, 2, 3); else WG_GO(10, 2, 2); }
 #undef WG_GO
     return hipGetLastError();
 }
