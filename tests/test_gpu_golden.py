@@ -170,11 +170,12 @@ def test_n2048_ntt_path_vs_generic_and_oracle():
             assert np.array_equal(fast.gate_bootstrapping_tlwe_to_tlwe(c), gen.gate_bootstrapping_tlwe_to_tlwe(c))
 
 
-@pytest.mark.parametrize("N,K,L", [(1024, 1, 2), (1024, 1, 3), (1024, 2, 2), (1024, 2, 3), (2048, 1, 2)])
+@pytest.mark.parametrize("N,K,L", [(512, 1, 2), (512, 1, 3), (512, 2, 3), (1024, 1, 2), (1024, 1, 3), (1024, 2, 2),
+                                   (1024, 2, 3), (2048, 1, 2)])
 def test_workgroup_ntt_sets_vs_generic_and_oracle(N, K, L):
-    """The other parameter sets with workgroup NTT kernels (split key; two waves per gate at
-    N = 1024) vs the O(N^2) wrap-around kernels vs the oracle, including key words at the ends of
-    the range, and a NAND end to end on generated keys."""
+    """The other parameter sets with workgroup NTT kernels (one wave per gate at N = 512, two at
+    N = 1024; split key except for (512, 1, 2)) vs the O(N^2) wrap-around kernels vs the oracle,
+    including key words at the ends of the range, and a NAND end to end on generated keys."""
     import tfhe_amd
 
     n = 4

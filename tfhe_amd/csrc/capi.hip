@@ -535,7 +535,9 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
         } else if (ctx->wg) {
             const TwiddleSet tw = make_twiddles(p->N);
             build_uniform(ctx->u, tw);
-            const std::vector<double> blk = p->N == 2048 ? build_tw_table_wg<11>(tw) : build_tw_table_wg<10>(tw);
+            const std::vector<double> blk = p->N == 2048   ? build_tw_table_wg<11>(tw)
+                                            : p->N == 1024 ? build_tw_table_wg<10>(tw)
+                                                           : build_tw_table_wg<9>(tw);
             wg_split(p->N, p->K, p->L, p->bg_bit, &ctx->parts, &ctx->shift);
             CTX_TRY(hipMalloc(&ctx->d_tw, blk.size() * sizeof(double)));
             CTX_TRY(hipMemcpy(ctx->d_tw, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));

@@ -1,4 +1,4 @@
-// Workgroup-cooperative exact negacyclic NTT of length N = 2^LOGN (N >= 1024) over the same
+// Workgroup-cooperative exact negacyclic NTT of length N = 2^LOGN (N >= 512) over the same
 // prime field and with the same FP64 modular arithmetic as ntt512.hpp.  N/8 threads transform
 // one polynomial: 8 coefficients per thread, groups of up to three radix-2 stages in registers,
 // a transpose through LDS between groups: with a block barrier and two alternating buffers where

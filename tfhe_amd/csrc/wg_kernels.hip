@@ -1,4 +1,5 @@
-// Blind rotation for ring degrees N >= 1024 (N = 2048 with K = 1, N = 1024 with K = 1 or 2):
+// Blind rotation for the parameter sets beside the default one (N = 2048 with K = 1, N = 1024 and
+// N = 512 with K = 1 or 2):
 // one workgroup of N/8 threads owns one gate and transforms every polynomial cooperatively
 // (ntt_wg.hpp).
 //
@@ -195,14 +196,19 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
 
 // ---- host side ---------------------------------------------------------------------------------
 
-// parameter sets with an instantiation (8-bit gadget): N = 2048 with K = 1 and N = 1024 with K = 1 or
-// 2, L = 2 or 3 each
+// parameter sets with an instantiation (8-bit gadget, L = 2 or 3): N = 2048 with K = 1, N = 1024 with
+// K = 1 or 2, and the N = 512 sets other than the default one (which has kernels of its own)
 bool wg_has_kernel(int N, int K, int L, int bg) {
     if (bg != 8 || (L != 2 && L != 3)) return false;
-    return (N == 2048 && K == 1) || (N == 1024 && (K == 1 || K == 2));
+    if (N == 2048) return K == 1;
+    if (N == 1024) return K == 1 || K == 2;
+    if (N == 512) return K == 1 || (K == 2 && L == 3);
+    return false;
 }
 
-int wg_table_pairs(int N) { return N == 2048 ? WgNtt<11>::TABLE_PAIRS : N == 1024 ? WgNtt<10>::TABLE_PAIRS : 0; }
+int wg_table_pairs(int N) {
+    return N == 2048 ? WgNtt<11>::TABLE_PAIRS : N == 1024 ? WgNtt<10>::TABLE_PAIRS : N == 512 ? WgNtt<9>::TABLE_PAIRS : 0;
+}
 
 // number of key parts and the split position for a parameter set: one part if the largest
 // accumulation (K+1) L N 2^(bg-1) 2^31 stays below p/2 with margin, else two halves of 16 bits
@@ -215,14 +221,14 @@ void wg_split(int N, int K, int L, int bg, int* parts, int* shift) {
 hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_polys,
                                   int N, int parts, int shift, hipStream_t stream) {
     if (n_polys == 0) return hipSuccess;
-    if (N == 2048)
-        bk_transform_wg_kernel<11><<<(unsigned)(n_polys * parts), WgNtt<11>::T, 0, stream>>>(u, table, bk, bk_ntt, parts,
-                                                                                             shift);
-    else if (N == 1024)
-        bk_transform_wg_kernel<10><<<(unsigned)(n_polys * parts), WgNtt<10>::T, 0, stream>>>(u, table, bk, bk_ntt, parts,
-                                                                                             shift);
-    else
-        return hipErrorInvalidValue;
+#define WG_KEY(LOGN)                                                                                                 \
+    bk_transform_wg_kernel<LOGN><<<(unsigned)(n_polys * parts), WgNtt<LOGN>::T, 0, stream>>>(u, table, bk, bk_ntt, parts, \
+                                                                                             shift)
+    if (N == 2048) WG_KEY(11);
+    else if (N == 1024) WG_KEY(10);
+    else if (N == 512) WG_KEY(9);
+    else return hipErrorInvalidValue;
+#undef WG_KEY
     return hipGetLastError();
 }
 
@@ -230,13 +236,18 @@ hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2
                                   const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L,
                                   int parts, int shift, int extract, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
-    if (!wg_has_kernel(N, K, L, 8) || parts != 2) return hipErrorInvalidValue;
-#define WG_GO(LOGN, KK, LL)                                                                                          \
-    blind_rotate_wg_kernel<LOGN, KK, LL, 2><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, \
-                                                                                              out, n, shift, extract)
-    if (N == 2048) { if (L == 3) WG_GO(11, 1, 3); else WG_GO(11, 1, 2); }
-    else if (K == 1) { if (L == 3) WG_GO(10, 1, 3); else WG_GO(10, 1, 2); }
-    else { if (L == 3) WG_GO(10, 2, 3); else WG_GO(10, 2, 2); }
+    if (!wg_has_kernel(N, K, L, 8)) return hipErrorInvalidValue;
+    int want_parts = 0, want_shift = 0;
+    wg_split(N, K, L, 8, &want_parts, &want_shift);
+    if (parts != want_parts) return hipErrorInvalidValue;
+#define WG_GO(LOGN, KK, LL, PP)                                                                                       \
+    blind_rotate_wg_kernel<LOGN, KK, LL, PP><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, \
+                                                                                               out, n, shift, extract)
+    if (N == 2048) { if (L == 3) WG_GO(11, 1, 3, 2); else WG_GO(11, 1, 2, 2); }
+    else if (N == 1024 && K == 1) { if (L == 3) WG_GO(10, 1, 3, 2); else WG_GO(10, 1, 2, 2); }
+    else if (N == 1024) { if (L == 3) WG_GO(10, 2, 3, 2); else WG_GO(10, 2, 2, 2); }
+    else if (K == 1) { if (L == 3) WG_GO(9, 1, 3, 2); else WG_GO(9, 1, 2, 1); }  // N = 512: only (1, 2) fits one part
+    else WG_GO(9, 2, 3, 2);
 #undef WG_GO
     return hipGetLastError();
 }
