@@ -193,7 +193,7 @@ int tfhe_amd_external_product_batch(const tfhe_amd_params* p, const uint32_t* tr
 int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* d0, const uint32_t* d1,
                         uint32_t* out, size_t batch, int device);
 
-/* Which blind-rotation kernels a context uses: "ntt512" (default parameter set: wave-per-gate and
+/* Which blind-rotation kernels a context uses: "ntt512" (default parameter set and N = 512, K = 1, L = 2: wave-per-gate and
  * workgroup-per-gate NTT kernels), "ntt-workgroup" (N = 2048 with K = 1, N = 1024 and other N = 512 sets with K = 1 or 2; L = 2 or 3), "generic" (exact O(N^2) kernels),
  * "reference-fft-wave" / "reference-fft-workgroup" (verification mode), or "none" (no bootstrapping
  * key).  For logs and for tests that must not pass on a slower path by accident. */

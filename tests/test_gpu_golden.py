@@ -190,7 +190,8 @@ def test_workgroup_ntt_sets_vs_generic_and_oracle(N, K, L):
     tv = rs.randint(0, 2**32, size=(K + 1, N), dtype=np.uint64).astype(np.uint32)
     for bk in keys:
         with tfhe_amd.Context(p, bk, None) as fast, tfhe_amd.Context(p, bk, None, generic_kernels=True) as gen:
-            assert fast.kernel_family() == "ntt-workgroup" and gen.kernel_family() == "generic"
+            assert fast.kernel_family() == ("ntt512" if (N, L) == (512, 2) else "ntt-workgroup")
+            assert gen.kernel_family() == "generic"
             for t in (None, tv):
                 got = fast.blind_rotate(c, t)
                 assert np.array_equal(got, gen.blind_rotate(c, t))
@@ -207,6 +208,27 @@ def test_workgroup_ntt_sets_vs_generic_and_oracle(N, K, L):
         got = ctx.nand(a, b)
     assert np.array_equal(got, O.Context(op, bk, ks).nand_batch(a, b))
     assert np.array_equal(O.decrypt_bits(got, s0, op), 1 - (bits_a & bits_b))
+
+
+def test_n512_k1_both_forms_vs_generic():
+    """N = 512, K = 1, L = 2 runs on the wave-per-gate kernels of the default set: throughput and
+    latency forms against the O(N^2) kernels, accumulator and extracted sample."""
+    import tfhe_amd
+
+    n = 9
+    p = tfhe_amd.Params(n, 512, 1, 8, 2, 5, 2)
+    rs = np.random.RandomState(12)
+    bk = rs.randint(0, 2**32, size=p.bk_shape(), dtype=np.uint64).astype(np.uint32)
+    c = rs.randint(0, 2**32, size=(70, n + 1), dtype=np.uint64).astype(np.uint32)
+    tv = rs.randint(0, 2**32, size=(2, 512), dtype=np.uint64).astype(np.uint32)
+    with tfhe_amd.Context(p, bk, None, generic_kernels=True) as gen:
+        want_acc, want_acc_tv, want_lv1 = gen.blind_rotate(c), gen.blind_rotate(c, tv), gen.gate_bootstrapping_tlwe_to_tlwe(c)
+    for form in ("throughput", "latency"):
+        with tfhe_amd.Context(p, bk, None, form=form) as ctx:
+            assert ctx.kernel_family() == "ntt512"
+            assert np.array_equal(ctx.blind_rotate(c), want_acc), form
+            assert np.array_equal(ctx.blind_rotate(c, tv), want_acc_tv), form
+            assert np.array_equal(ctx.gate_bootstrapping_tlwe_to_tlwe(c), want_lv1), form
 
 
 def test_config5_n2048_nand_vs_oracle():

@@ -64,7 +64,7 @@ constexpr int kTimingRing = 256;
 struct tfhe_amd_ctx {
     tfhe_amd_params p{};
     int device = 0;
-    bool fast = false;             // specialised NTT kernels (N = 512, K = 2, L = 2, 8-bit gadget)
+    bool fast = false;             // specialised NTT kernels (N = 512, K = 1 or 2, L = 2, 8-bit gadget)
     bool wg = false;               // workgroup-cooperative NTT kernels (N = 2048 set)
     bool replica = false;          // products through a replay of the reference's FFT (verification)
     bool replica_generic = false;  // ... with the one-workgroup-per-gate kernel even at the default set
@@ -110,7 +110,9 @@ bool params_sane(const tfhe_amd_params* p) {
     return true;
 }
 
-bool fast_supported(const tfhe_amd_params* p) { return p->N == 512 && p->K == 2 && p->L == 2 && p->bg_bit == 8; }
+bool fast_supported(const tfhe_amd_params* p) {
+    return p->N == 512 && (p->K == 1 || p->K == 2) && p->L == 2 && p->bg_bit == 8;
+}
 
 void build_uniform(NttUniform& u, const TwiddleSet& t) {
     u.p = (double)kP;

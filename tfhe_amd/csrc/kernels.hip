@@ -218,7 +218,7 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
             }
 #if TFHE_AMD_PAIR_THROUGHPUT
             {
-                static_assert(L == 2 && K1 == 3, "the two levels of a digit polynomial run as one interleaved pair");
+                static_assert(L == 2 && (K1 == 2 || K1 == 3), "the two levels of a digit polynomial run as one interleaved pair");
                 double x0[8], x1[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
@@ -248,7 +248,8 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
                 ntt512_forward2_small(x0, x1, u, s_tw, tr, tr2, lane, [&]() {
                     mac(x0);
                     // every product is at most 1.41 p: three sum to <= 4.24 p; reducing after the third
-                    // of the six keeps the running sum below 0.5 p + 4.24 p = 4.74 p < 2^53 = 5.26 p
+                    // of the six (or four, K = 1) keeps the running sum below 0.5 p + 4.24 p = 4.74 p
+                    // < 2^53 = 5.26 p
                     if (q == 1) {
 #pragma unroll
                         for (int col = 0; col < K1; col++)
@@ -315,16 +316,20 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
         }
         // |out| <= 4.74 p
 #if TFHE_AMD_PAIR_THROUGHPUT
-        static_assert(K1 == 3, "inverse transforms run as one pair and one single");
         ntt512_inverse2(out[0], out[1], u, s_tw, tr, tr2, lane);
-        // the accumulator updates of the first two columns run while the third transform's
-        // transpositions are in flight
         auto update = [&](int col) {
 #pragma unroll
             for (int k = 0; k < 8; k++) acc[col][64 * k + lane] += to_torus(out[col][k], p, pinv);
         };
-        ntt512_inverse_overlapped(out[2], u, s_tw, tr, lane, [&]() { update(0); }, [&]() { update(1); });
-        update(2);
+        if constexpr (K1 == 3) {
+            // the accumulator updates of the first two columns run while the third transform's
+            // transpositions are in flight
+            ntt512_inverse_overlapped(out[2], u, s_tw, tr, lane, [&]() { update(0); }, [&]() { update(1); });
+            update(2);
+        } else {
+            update(0);
+            update(1);
+        }
 #else
 #pragma unroll
         for (int col = 0; col < K1; col++) {
@@ -802,15 +807,19 @@ hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* 
                                    const uint32_t* tv, uint32_t* out, int n_gates, int n, int K, int L, int extract,
                                    int form, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
-    if (!(K == 2 && L == 2)) return hipErrorInvalidValue;
+    if (!((K == 1 || K == 2) && L == 2)) return hipErrorInvalidValue;
     const bool latency = form == 1 || (form == 0 && n_gates <= kLatencyMaxGates);
-    if (latency) {
+    const unsigned blocks = (unsigned)((n_gates + 3) / 4);
+    if (latency && K == 2)
         blind_rotate_512_latency_kernel<2, 2><<<(unsigned)n_gates, 128 * 6, 0, stream>>>(u, tw + kTwPairs, bk_ntt, c, tv,
                                                                                        out, n_gates, n, extract);
-    } else {
-        const unsigned blocks = (unsigned)((n_gates + 3) / 4);
+    else if (latency)
+        blind_rotate_512_latency_kernel<1, 2><<<(unsigned)n_gates, 128 * 4, 0, stream>>>(u, tw + kTwPairs, bk_ntt, c, tv,
+                                                                                       out, n_gates, n, extract);
+    else if (K == 2)
         blind_rotate_512_kernel<2, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, tv, out, n_gates, n, extract);
-    }
+    else
+        blind_rotate_512_kernel<1, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, tv, out, n_gates, n, extract);
     return hipGetLastError();
 }
 

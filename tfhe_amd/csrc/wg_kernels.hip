@@ -197,12 +197,12 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
 // ---- host side ---------------------------------------------------------------------------------
 
 // parameter sets with an instantiation (8-bit gadget, L = 2 or 3): N = 2048 with K = 1, N = 1024 with
-// K = 1 or 2, and the N = 512 sets other than the default one (which has kernels of its own)
+// K = 1 or 2, and N = 512 with L = 3 (the N = 512 sets with L = 2 have wave-per-gate kernels)
 bool wg_has_kernel(int N, int K, int L, int bg) {
     if (bg != 8 || (L != 2 && L != 3)) return false;
     if (N == 2048) return K == 1;
     if (N == 1024) return K == 1 || K == 2;
-    if (N == 512) return K == 1 || (K == 2 && L == 3);
+    if (N == 512) return L == 3;  // L = 2: wave-per-gate kernels (kernels.hip)
     return false;
 }
 
@@ -246,7 +246,7 @@ hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2
     if (N == 2048) { if (L == 3) WG_GO(11, 1, 3, 2); else WG_GO(11, 1, 2, 2); }
     else if (N == 1024 && K == 1) { if (L == 3) WG_GO(10, 1, 3, 2); else WG_GO(10, 1, 2, 2); }
     else if (N == 1024) { if (L == 3) WG_GO(10, 2, 3, 2); else WG_GO(10, 2, 2, 2); }
-    else if (K == 1) { if (L == 3) WG_GO(9, 1, 3, 2); else WG_GO(9, 1, 2, 1); }  // N = 512: only (1, 2) fits one part
+    else if (K == 1) WG_GO(9, 1, 3, 2);
     else WG_GO(9, 2, 3, 2);
 #undef WG_GO
     return hipGetLastError();

@@ -1,5 +1,5 @@
-"""Throughput of parameter sets on the workgroup NTT kernels (n = 630, T = 8), random keys, device
-resident; the exact O(N^2) kernels beside them."""
+"""Throughput of the parameter sets beside the default one that have NTT kernels (n = 630, T = 8),
+random keys, device resident; the exact O(N^2) kernels beside them."""
 import sys
 import time
 
@@ -14,7 +14,7 @@ for N, K, L in ((512, 1, 2), (512, 2, 3), (1024, 1, 2), (1024, 1, 3), (1024, 2, 
     rs = np.random.RandomState(0)
     bk = rs.randint(0, 2**32, size=p.bk_shape(), dtype=np.uint64).astype(np.uint32)
     ks = rs.randint(0, 2**32, size=p.ks_shape(), dtype=np.uint64).astype(np.uint32)
-    for kw, sizes in (({}, (1, 4096)), ({"generic_kernels": True}, (256,))):
+    for kw, sizes in (({}, (1, 8192)), ({"generic_kernels": True}, (256,))):
         with tfhe_amd.Context(p, bk, ks, **kw) as ctx:
             ctx.enable_timing(True)
             for G in sizes:
