@@ -193,10 +193,15 @@ int tfhe_amd_external_product_batch(const tfhe_amd_params* p, const uint32_t* tr
 int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* d0, const uint32_t* d1,
                         uint32_t* out, size_t batch, int device);
 
-/* Which blind-rotation kernels a context uses: "ntt512" (default parameter set and N = 512, K = 1, L = 2: wave-per-gate and
- * workgroup-per-gate NTT kernels), "ntt-workgroup" (N = 2048 with K = 1, N = 1024 and other N = 512 sets with K = 1 or 2; L = 2 or 3), "generic" (exact O(N^2) kernels),
- * "reference-fft-wave" / "reference-fft-workgroup" (verification mode), or "none" (no bootstrapping
- * key).  For logs and for tests that must not pass on a slower path by accident. */
+/* Which blind-rotation kernels a context uses:
+ *   "ntt512"         N = 512 with L = 2 (the default set, and K = 1): wave-per-gate and
+ *                    workgroup-per-gate NTT kernels
+ *   "ntt-workgroup"  N = 2048 with K = 1, N = 1024 with K = 1 or 2, N = 512 with L = 3 (L = 2 or 3,
+ *                    8-bit gadget)
+ *   "generic"        exact O(N^2) kernels, any parameter set
+ *   "reference-fft-wave" / "reference-fft-workgroup"   verification mode
+ *   "none"           the context holds no bootstrapping key
+ * For logs and for tests that must not pass on a slower path by accident. */
 const char* tfhe_amd_ctx_kernel_family(const tfhe_amd_ctx* ctx);
 
 /* Blocks until everything enqueued on the context's own stream has finished. */
