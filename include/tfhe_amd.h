@@ -69,7 +69,8 @@ enum {
                                          specialised NTT kernel exists (cross-checking) */
     /* The specialised blind rotation has two forms with identical results: one gate per wave
      * (throughput) and one gate per workgroup (latency).  By default batches of at most 512 gates
-     * take the latency form; these flags pin one form. */
+     * take the latency form; these flags pin one form.  They apply to the "ntt512" kernel family
+     * (tfhe_amd_ctx_kernel_family) and are ignored by the others, which have one form. */
     TFHE_AMD_CTX_LATENCY_FORM = 4,
     TFHE_AMD_CTX_THROUGHPUT_FORM = 8,
     /* Verification mode.  The reference multiplies polynomials with a double-precision FFT
