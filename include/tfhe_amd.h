@@ -118,6 +118,19 @@ int tfhe_amd_nand_batch(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b,
 int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
                                size_t n_gates, void* stream);
 
+/* No counterpart in the reference.  tfhe_amd_nand_batch_device for callers that cannot allocate:
+ * code under HIP graph capture, serving loops and harnesses that forbid hipMalloc.  Same arguments,
+ * same results, but the call performs no device or host allocation: its workspace (the combined
+ * inputs and the lv1 ciphertexts, (n+1) + (N*K+1) words per gate) is a static device array of
+ * TFHE_AMD_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
+ * Batches whose workspace exceeds it (more than 2,523 gates at the default parameters) are rejected
+ * with TFHE_AMD_ERR_ARGUMENT.  All contexts on one GPU share that GPU's array: calls that overlap
+ * in time on one GPU race, whatever their contexts or streams; the caller orders them.  Kernel
+ * timing (tfhe_amd_ctx_enable_timing) does not record these calls. */
+#define TFHE_AMD_NOALLOC_SCRATCH_BYTES ((size_t)16 << 20)
+int tfhe_amd_nand_batch_device_noalloc(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                                       size_t n_gates, void* stream);
+
 /* The other two-input gates.  The reference has NAND only; each gate below is the same bootstrap
  * and key switch behind another linear pre-combination, c = (offset, 0, ..) + sa*a + sb*b, of which
  * reference src/hom_nand.hpp:76-78 is the NAND instance (true = +1/8, false = -1/8, reference

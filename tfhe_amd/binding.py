@@ -92,6 +92,7 @@ def library():
     lib.tfhe_amd_ctx_destroy.restype = None
     lib.tfhe_amd_nand_batch.argtypes = [vp, vp, vp, vp, sz]
     lib.tfhe_amd_nand_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.tfhe_amd_nand_batch_device_noalloc.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.tfhe_amd_gate_batch.argtypes = [vp, i32, vp, vp, vp, sz]
     lib.tfhe_amd_gate_batch_device.argtypes = [vp, i32, vp, vp, vp, sz, vp]
     lib.tfhe_amd_gates_batch_device.argtypes = [vp, vp, vp, vp, vp, sz, vp]
@@ -324,6 +325,18 @@ class Context:
         w = g * self.params.n1
         _check(library().tfhe_amd_nand_batch_device(self._h, _dev_ptr(a, w), _dev_ptr(b, w), _dev_ptr(out, w), g,
                                                     self._stream_ptr(stream)))
+        return out
+
+    NOALLOC_SCRATCH_BYTES = 16 << 20
+
+    def nand_device_noalloc(self, a, b, out, stream=None):
+        """nand_device through the entry point that allocates nothing: the workspace is a static
+        device array (NOALLOC_SCRATCH_BYTES per GPU, shared by every context on it), larger batches
+        are rejected, and calls that overlap on one GPU race."""
+        g = a.shape[0]
+        w = g * self.params.n1
+        _check(library().tfhe_amd_nand_batch_device_noalloc(self._h, _dev_ptr(a, w), _dev_ptr(b, w), _dev_ptr(out, w),
+                                                            g, self._stream_ptr(stream)))
         return out
 
     def gate_device(self, op, a, b, out, stream=None):

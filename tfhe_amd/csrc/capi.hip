@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -59,6 +60,31 @@ struct DevBuf {
 
 constexpr int kTimingRing = 256;
 
+// Workspace of tfhe_amd_nand_batch_device_noalloc: the combined inputs c [G][n+1] and the lv1
+// results [G][N*K+1] of one call.  Every GPU the library runs on holds its own copy of this array
+// for the life of the process; the name below is only a host-side handle, the address on a device
+// comes from hipGetSymbolAddress with that device current (scratch_of).
+constexpr size_t kNoAllocWords = TFHE_AMD_NOALLOC_SCRATCH_BYTES / sizeof(uint32_t);
+__device__ __align__(256) uint32_t scratch[kNoAllocWords];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+uint32_t* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on GPU `device`, which must be the current device.  Resolved once per device.
+hipError_t scratch_of(int device, uint32_t** out) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<uint32_t*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 }  // namespace
 
 struct tfhe_amd_ctx {
@@ -82,6 +108,7 @@ struct tfhe_amd_ctx {
     uint32_t* d_c = nullptr;
     uint32_t* d_lv1 = nullptr;
     size_t ws_gates = 0;
+    uint32_t* d_scratch = nullptr;  // this device's copy of the static no-allocation workspace
     // The workspace is shared by all calls on this context.  Calls enqueued on different streams
     // are ordered through this event: every call records it behind its last kernel, and a call on
     // another stream waits for it before touching the workspace.
@@ -345,10 +372,11 @@ int run_key_switch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t
 // n_gates gates are MUXes: c holds n_gates + n_mux rows, and the lv1 result of row n_gates + j is
 // added (plus 1/8) to that of row n_gates - n_mux + j before the key switch.
 int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s,
-                  size_t n_mux = 0) {
+                  size_t n_mux = 0, uint32_t* lv1_ws = nullptr) {
+    uint32_t* const d_lv1 = lv1_ws ? lv1_ws : ctx->d_lv1;
     hipEvent_t* e = nullptr;
     // (the combination kernels that fill `c` ran on `s` already, after workspace_acquire)
-    if (ctx->timing) {
+    if (ctx->timing && !lv1_ws) {  // draining the event ring may block: not on the no-allocation path
         if (ctx->ev_count == kTimingRing) {
             int rc = drain_timing(ctx, kTimingRing - 1);
             if (rc) return rc;
@@ -356,18 +384,19 @@ int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_
         e = &ctx->ev[(size_t)((ctx->ev_head + ctx->ev_count) % kTimingRing) * 3];
         HIP_TRY(hipEventRecord(e[0], s));
     }
-    int rc = run_blind_rotate(ctx, c, nullptr, ctx->d_lv1, n_gates + n_mux, 1, s);
+    int rc = run_blind_rotate(ctx, c, nullptr, d_lv1, n_gates + n_mux, 1, s);
     if (rc) return rc;
     if (n_mux)
-        HIP_TRY(launch_mux_sum(ctx->d_lv1 + (n_gates - n_mux) * lv1_of(ctx), ctx->d_lv1 + n_gates * lv1_of(ctx), n_mux,
+        HIP_TRY(launch_mux_sum(d_lv1 + (n_gates - n_mux) * lv1_of(ctx), d_lv1 + n_gates * lv1_of(ctx), n_mux,
                                (int)lv1_of(ctx), s));
     if (e) HIP_TRY(hipEventRecord(e[1], s));
-    rc = run_key_switch(ctx, ctx->d_lv1, out, n_gates, s);
+    rc = run_key_switch(ctx, d_lv1, out, n_gates, s);
     if (rc) return rc;
     if (e) {
         HIP_TRY(hipEventRecord(e[2], s));
         ctx->ev_count++;
     }
+    if (lv1_ws) return TFHE_AMD_OK;  // the static workspace is not ordered through the context
     HIP_TRY(hipEventRecord(ctx->ws_done, s));
     ctx->ws_stream = s;
     ctx->ws_used = true;
@@ -503,6 +532,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     } while (0)
 
     CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CTX_TRY(scratch_of(device, &ctx->d_scratch));
     const size_t bk_words = tfhe_amd_bk_words(p), ks_words = tfhe_amd_ks_words(p);
     const int n1 = p->n + 1, nlv1 = p->N * p->K;
     DevBuf up_bk, up_ks;  // upload scratch for host-resident keys
@@ -684,6 +714,25 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
     if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
     HIP_TRY(launch_nand_combine(ctx->d_c, a, b, n_gates, ctx->p.n + 1, s));
     return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
+}
+
+int tfhe_amd_nand_batch_device_noalloc(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                                       size_t n_gates, void* stream) {
+    int rc = check_batch(ctx, n_gates, a && b && out);
+    if (rc || n_gates == 0) return rc;
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
+    const size_t n1 = n1_of(ctx), per_gate = n1 + lv1_of(ctx);
+    if (n_gates > kNoAllocWords / per_gate)
+        return fail(TFHE_AMD_ERR_ARGUMENT, "batch of " + std::to_string(n_gates) + " gates exceeds the static workspace (" +
+                                               std::to_string(kNoAllocWords / per_gate) +
+                                               " gates at this parameter set); use tfhe_amd_nand_batch_device");
+    if (!ctx->d_scratch) return fail(TFHE_AMD_ERR_HIP, "static workspace unresolved on this device");
+    DeviceGuard guard(ctx->device);
+    hipStream_t s = pick_stream(ctx, stream);
+    uint32_t* const d_c = ctx->d_scratch;
+    uint32_t* const d_lv1 = ctx->d_scratch + n_gates * n1;
+    HIP_TRY(launch_nand_combine(d_c, a, b, n_gates, (int)n1, s));
+    return run_bootstrap(ctx, d_c, out, n_gates, s, 0, d_lv1);
 }
 
 int tfhe_amd_gate_batch_device(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
