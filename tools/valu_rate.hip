@@ -11,7 +11,7 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1);} } while (0)
 
-constexpr int ITER = 512;
+constexpr int ITER = 16384;   // ~1.3 M instructions per wave: long enough for HIP events and for the clock to settle
 constexpr int UNROLL = 16;   // instructions per loop body (8 accumulators x 2)
 
 #define BODY8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, double seed, 
     unsigned m0 = iseed | 1, m1 = iseed ^ 0x55aa55aa;
     __syncthreads();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     for (int it = 0; it < ITER; it++) {
 #define F64_FMA(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(c0), "v"(c1));
@@ -99,7 +100,9 @@ __global__ void __launch_bounds__(1024) k(unsigned long long* out, double seed, 
         if constexpr (KIND == 34) { RUN(DOT4) }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = r1 - r0;   // 100 MHz constant clock
     double s = 0; unsigned us = 0; unsigned long long qs = 0;
     for (int i = 0; i < 8; i++) { s += d[i]; us ^= u[i]; qs ^= q[i]; }
     if (s == 1.2345 && us == 77 && qs == 3) out[1] = 1;   // keep results live
@@ -113,22 +116,50 @@ static const char* names[] = {"v_fma_f64","v_mul_f64","v_add_f64","v_rndne_f64",
   "v_add_u32_dpp","v_permlane32_swap","v_permlane16_swap","ds_swizzle+wait","ds_bpermute+wait","v_mov_b64","v_lshlrev_b64",
   "v_max_f64","v_fract_f64","v_floor_f64","v_ldexp_f64","cmp_f64+cndmask (2 instr)","v_bfe_u32","v_mul_i32_i24","v_dot4_i32_i8"};
 
+// Shader cycles per s_memtime tick: s_nop 15 occupies the wave for exactly 16 cycles, so a chain of
+// them counts shader cycles; s_memrealtime (100 MHz, constant) gives wall time.
+__global__ void __launch_bounds__(64) calib(unsigned long long* out, int reps) {
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < reps; it++) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+                     "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
+static double g_cycles_per_tick = 1.0;
+
 template <int KIND> void run(unsigned long long* dbuf, int ncu) {
     std::vector<unsigned long long> h(2 + ncu * 16);
     printf("%-28s", names[KIND]);
     for (int wps : {1, 2, 4}) {
         int threads = 64 * 4 * wps;
         CHECK(hipMemset(dbuf, 0, h.size() * 8));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
         k<KIND><<<ncu, threads>>>(dbuf, 1.000001, 12345u);
+        CHECK(hipEventRecord(e0));
         k<KIND><<<ncu, threads>>>(dbuf, 1.000001, 12345u);
+        CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        CHECK(hipEventDestroy(e0));
+        CHECK(hipEventDestroy(e1));
         CHECK(hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost));
         std::vector<double> cyc;
         for (int b = 0; b < ncu; b++) for (int w = 0; w < 4 * wps; w++) cyc.push_back((double)h[2 + b * 16 + w]);
         std::sort(cyc.begin(), cyc.end());
         double med = cyc[cyc.size() / 2];
-        // cycles per wave-instruction per SIMD
-        printf("  wps=%d: %7.2f", wps, med / (double)(ITER * UNROLL) / wps);
+        // ticks and nanoseconds per wave-instruction per SIMD
+        printf("  wps=%d: %5.2f ticks %5.3f ns", wps, med / (double)(ITER * UNROLL) / wps,
+               (double)ms * 1e6 / (double)(ITER * UNROLL) / wps);
     }
     printf("\n");
 }
@@ -139,7 +170,20 @@ int main() {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     printf("device %s CUs %d clock %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
     unsigned long long* d; CHECK(hipMalloc(&d, (2 + 1024 * 16) * 8));
-    printf("cycles (s_memtime ticks) per wave64 instruction per SIMD; each kernel: one block per CU\n");
+    {
+        const int reps = 20000;
+        unsigned long long hc[2];
+        calib<<<1, 64>>>(d, reps);
+        calib<<<1, 64>>>(d, reps);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(hc, d, 16, hipMemcpyDeviceToHost));
+        const double cycles = 16.0 * 16.0 * reps;
+        g_cycles_per_tick = cycles / (double)hc[0];
+        printf("calibration (one idle-GPU wave, %d x 16 s_nop 15 = %.0f shader cycles): %llu s_memtime ticks, %llu s_memrealtime "
+               "ticks of 10 ns -> %.3f cycles per s_memtime tick, s_memtime at %.1f MHz, shader clock %.0f MHz\n",
+               reps, cycles, hc[0], hc[1], g_cycles_per_tick, (double)hc[0] / ((double)hc[1] * 0.01), cycles / ((double)hc[1] * 0.01));
+    }
+    printf("s_memtime ticks and wall nanoseconds (HIP events around the launch) per wave64 instruction per SIMD; each kernel: one block per CU\n");
     run_all<0>(d, p.multiProcessorCount);
     return 0;
 }
