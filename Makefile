@@ -14,7 +14,7 @@ tfhe_amd/libtfhe_amd.so: $(SRC) $(HDR)
 # behavioural tests of the drop-in headers (src/*.hpp) on top of the library
 DROPIN_HDR := $(wildcard src/*.hpp)
 tests/cpp/dropin_test: tests/cpp/test_dropin.cpp tests/cpp/test_dropin_tu2.cpp $(DROPIN_HDR) tfhe_amd/libtfhe_amd.so
-	g++ -std=gnu++17 -O2 -Wall -I src -I include tests/cpp/test_dropin.cpp tests/cpp/test_dropin_tu2.cpp -o $@ \
+	g++ -std=gnu++17 -O2 -Wall -pthread -I src -I include tests/cpp/test_dropin.cpp tests/cpp/test_dropin_tu2.cpp -o $@ \
 	    -L tfhe_amd -ltfhe_amd -Wl,-rpath,'$$ORIGIN/../../tfhe_amd'
 
 oracle:

@@ -6,8 +6,11 @@
  * and the functions under it, bind to when evaluation is moved to the GPU.  All pointers are
  * plain arrays of uint32_t torus words in the flat layouts described next; no C++ or torch
  * type crosses this boundary.  Every call returns an int status (0 = success) and never
- * throws.  A context may be used from one host thread at a time; calls enqueued on different
- * streams through one context share its workspace and are ordered one behind the other.
+ * throws.  A context may be used from several host threads at once, as the reference's nand() may
+ * be called concurrently on one shared EvaluateKey: every call that needs scratch memory takes one
+ * of up to eight workspaces of the context for its duration (host-pointer calls) or while it
+ * enqueues (device-pointer calls; calls that reuse a workspace on another stream are ordered one
+ * behind the other).  tfhe_amd_ctx_destroy must not race with calls on the same context.
  *
  * Flat layouts (row-major):
  *   lv0 ciphertext    [n+1]                      = [b, a_0 .. a_{n-1}]   (reference src/hom_nand.hpp:43,
@@ -206,6 +209,35 @@ int tfhe_amd_external_product_batch(const tfhe_amd_params* p, const uint32_t* tr
                                     uint32_t* out, size_t batch, int device);
 int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* d0, const uint32_t* d1,
                         uint32_t* out, size_t batch, int device);
+
+/* Several GPUs of one node behind one handle, for a single-process caller (the reference's only
+ * kind: test/main.cpp:180-224).  Gates share nothing but the read-only keys (reference
+ * src/hom_nand.hpp:74-81), so a batch is split in contiguous blocks, device g of P evaluating gates
+ * [g G / P, (g + 1) G / P), with no exchange between devices while evaluating.  device_ids lists the
+ * GPUs (an id may appear more than once: each entry gets a context of its own).  The raw keys are
+ * uploaded to the first device once (with TFHE_AMD_CTX_KEYS_ON_DEVICE they are already there),
+ * copied device to device to the others, and every device transforms its own copy. */
+typedef struct tfhe_amd_multi_ctx tfhe_amd_multi_ctx;
+int tfhe_amd_multi_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint32_t* ks, const int* device_ids,
+                              int n_devices, unsigned flags, tfhe_amd_multi_ctx** out);
+void tfhe_amd_multi_ctx_destroy(tfhe_amd_multi_ctx* m);
+int tfhe_amd_multi_ctx_device_count(const tfhe_amd_multi_ctx* m);
+/* The context of entry `index` of the device list (owned by m), for the single-device calls above. */
+tfhe_amd_ctx* tfhe_amd_multi_ctx_get(tfhe_amd_multi_ctx* m, int index);
+/* The block of a batch of n_gates that entry `index` evaluates: gates [*begin, *end). */
+void tfhe_amd_multi_shard(const tfhe_amd_multi_ctx* m, size_t n_gates, int index, size_t* begin, size_t* end);
+/* HomNAND::nand / the other gates / the bare bootstrap over a batch in HOST memory, all devices
+ * working side by side (one host thread per device inside the call).  Synchronous. */
+int tfhe_amd_multi_nand_batch(tfhe_amd_multi_ctx* m, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                              size_t n_gates);
+int tfhe_amd_multi_gate_batch(tfhe_amd_multi_ctx* m, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                              size_t n_gates);
+int tfhe_amd_multi_bootstrap_batch(tfhe_amd_multi_ctx* m, const uint32_t* c, uint32_t* out, size_t n_gates);
+/* Device-resident form: a[g], b[g], out[g] are arrays of n_gates[g] ciphertexts in the memory of
+ * entry g's GPU.  Enqueued on every context's own stream; tfhe_amd_multi_ctx_synchronize waits. */
+int tfhe_amd_multi_nand_batch_device(tfhe_amd_multi_ctx* m, const uint32_t* const* a, const uint32_t* const* b,
+                                     uint32_t* const* out, const size_t* n_gates);
+int tfhe_amd_multi_ctx_synchronize(tfhe_amd_multi_ctx* m);
 
 /* Which blind-rotation kernels a context uses:
  *   "ntt512"         N = 512 with L = 2 (the default set, and K = 1): wave-per-gate and

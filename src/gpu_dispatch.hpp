@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <list>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -29,6 +31,28 @@ inline void check(int rc, const char* what) {
 inline int& device() {  // GPU used by the header-level calls; change before the first evaluation
     static int dev = 0;
     return dev;
+}
+
+// GPUs that the batch calls (HomNAND::nand_batch, gate_batch) spread their gates over, in
+// contiguous blocks; empty (the default) = device() alone.  Single-gate calls run on the first GPU
+// of the list.  Initial value: the environment variable TFHE_AMD_DEVICES, a comma-separated list
+// ("0,1,2,3").  Change before the first evaluation with a key, or call cache().clear().
+inline std::vector<int>& devices() {
+    static std::vector<int> devs = [] {
+        std::vector<int> v;
+        if (const char* e = std::getenv("TFHE_AMD_DEVICES")) {
+            const char* q = e;
+            while (*q) {
+                char* end = nullptr;
+                const long d = std::strtol(q, &end, 10);
+                if (end == q) break;
+                v.push_back((int)d);
+                q = (*end == ',') ? end + 1 : end;
+            }
+        }
+        return v;
+    }();
+    return devs;
 }
 
 // Context flags (TFHE_AMD_CTX_*) for the contexts the headers create.  Setting
@@ -96,8 +120,27 @@ Vector<Polynomial<TorusValue, N>, K1> take_trlwe(const uint32_t* src) {
 }
 
 // ---- context cache ---------------------------------------------------------------------------
-// Keyed on the addresses of the caller's key objects plus a fingerprint of their contents, so a
-// key that is destroyed and another built at the same address is detected.
+// The device copy of a key: one context on device(), or one per GPU of devices().  Handed out as
+// shared_ptr so that an entry evicted by one thread stays alive while another thread evaluates on it.
+struct DeviceKey {
+    tfhe_amd_ctx* single = nullptr;
+    tfhe_amd_multi_ctx* multi = nullptr;
+    DeviceKey() = default;
+    DeviceKey(const DeviceKey&) = delete;
+    DeviceKey& operator=(const DeviceKey&) = delete;
+    ~DeviceKey() {
+        if (multi) tfhe_amd_multi_ctx_destroy(multi);
+        if (single) tfhe_amd_ctx_destroy(single);
+    }
+    // the context single-gate and lower-level calls run on
+    tfhe_amd_ctx* ctx() const { return multi ? tfhe_amd_multi_ctx_get(multi, 0) : single; }
+};
+
+// Keyed on the addresses of the caller's key objects, the device list and the context flags, plus a
+// fingerprint of the key contents (words sampled across the whole key), so that a key destroyed and
+// another built at the same address is detected.  A key modified in place between two evaluations
+// is detected only if a sampled word changed: call invalidate() after editing a key.  get() may be
+// called from several threads at once, as the reference's nand() may on one shared EvaluateKey.
 class ContextCache {
     struct Entry {
         const void* bk_id;
@@ -105,8 +148,10 @@ class ContextCache {
         uint64_t print;
         tfhe_amd_params params;
         unsigned flags;
-        tfhe_amd_ctx* ctx;
+        std::vector<int> devs;
+        std::shared_ptr<DeviceKey> key;
     };
+    std::mutex mutex_;
     std::list<Entry> entries_;
     static constexpr size_t kMaxEntries = 4;
 
@@ -114,40 +159,53 @@ class ContextCache {
         return a.n == b.n && a.N == b.N && a.K == b.K && a.bg_bit == b.bg_bit && a.L == b.L && a.T == b.T &&
                a.base_bit == b.base_bit;
     }
+    static std::vector<int> device_list() {
+        return devices().empty() ? std::vector<int>{device()} : devices();
+    }
 
 public:
-    ~ContextCache() { clear(); }
     void clear() {
-        for (auto& e : entries_) tfhe_amd_ctx_destroy(e.ctx);
-        entries_.clear();
+        std::lock_guard<std::mutex> lock(mutex_);
+        entries_.clear();  // contexts still in use elsewhere die with their last user
+    }
+    // forget the device copy of the key objects at these addresses (after editing a key in place)
+    void invalidate(const void* bk_id, const void* ks_id) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        entries_.remove_if([&](const Entry& e) { return e.bk_id == bk_id && e.ks_id == ks_id; });
     }
 
     // `print`: cheap fingerprint of the key contents; `make_bk` / `make_ks`: produce the flat keys
-    // (an empty vector = that key is absent); only called on a miss.
+    // (an empty vector = that key is absent); only called on a miss.  The lock is held while a
+    // missing context is built, so that threads starting together on one key build it once.
     template <typename MakeBk, typename MakeKs>
-    tfhe_amd_ctx* get(const tfhe_amd_params& params, const void* bk_id, const void* ks_id, uint64_t print,
-                      MakeBk make_bk, MakeKs make_ks) {
+    std::shared_ptr<DeviceKey> get(const tfhe_amd_params& params, const void* bk_id, const void* ks_id, uint64_t print,
+                                   MakeBk make_bk, MakeKs make_ks) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        const std::vector<int> devs = device_list();
+        const unsigned flags = context_flags();
         for (auto it = entries_.begin(); it != entries_.end(); ++it)
-            if (it->bk_id == bk_id && it->ks_id == ks_id && same(it->params, params) && it->flags == context_flags()) {
+            if (it->bk_id == bk_id && it->ks_id == ks_id && same(it->params, params) && it->flags == flags &&
+                it->devs == devs) {
                 if (it->print == print) {
                     entries_.splice(entries_.begin(), entries_, it);
-                    return entries_.front().ctx;
+                    return entries_.front().key;
                 }
-                tfhe_amd_ctx_destroy(it->ctx);  // same address, different contents
-                entries_.erase(it);
+                entries_.erase(it);  // same address, different contents
                 break;
             }
         const std::vector<uint32_t> bk = make_bk(), ks = make_ks();
-        tfhe_amd_ctx* ctx = nullptr;
-        check(tfhe_amd_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(),
-                                  device(), context_flags(), &ctx),
-              "tfhe_amd_ctx_create");
-        entries_.push_front(Entry{bk_id, ks_id, print, params, context_flags(), ctx});
-        if (entries_.size() > kMaxEntries) {
-            tfhe_amd_ctx_destroy(entries_.back().ctx);
-            entries_.pop_back();
-        }
-        return ctx;
+        auto key = std::make_shared<DeviceKey>();
+        if (devs.size() > 1)
+            check(tfhe_amd_multi_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(),
+                                            devs.data(), (int)devs.size(), flags, &key->multi),
+                  "tfhe_amd_multi_ctx_create");
+        else
+            check(tfhe_amd_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(), devs[0],
+                                      flags, &key->single),
+                  "tfhe_amd_ctx_create");
+        entries_.push_front(Entry{bk_id, ks_id, print, params, flags, devs, key});
+        if (entries_.size() > kMaxEntries) entries_.pop_back();
+        return key;
     }
 };
 
@@ -156,20 +214,22 @@ inline ContextCache& cache() {
     return c;
 }
 
-// fingerprint helpers: a few words sampled across the key
+// fingerprint helpers: one word of every row of every TRGSW sample / of every (coefficient, level)
+// block of the key-switching key, at a position that moves with the row (about 9,000 words of the
+// default keys, a few tens of microseconds)
 inline uint64_t mix(uint64_t h, uint32_t v) { return (h ^ v) * 0x100000001B3ULL; }
 template <int N, int R, int K1, int TLWE_N>
 uint64_t fingerprint(const Vector<Matrix<Polynomial<TorusValue, N>, R, K1>, TLWE_N>& bk) {
     uint64_t h = 0xCBF29CE484222325ULL;
-    for (int i = 0; i < TLWE_N; i += (TLWE_N > 16 ? TLWE_N / 16 : 1))
-        for (int r = 0; r < R; r++) h = mix(h, bk[i][r][K1 - 1][(i * 7 + r) % N].get_raw_value());
+    for (int i = 0; i < TLWE_N; i++)
+        for (int r = 0; r < R; r++) h = mix(h, bk[i][r][(i + r) % K1][(i * 7 + r * 31) % N].get_raw_value());
     return h;
 }
 template <int W, int B, int T, int N_LV1>
 uint64_t fingerprint(const Vector<Vector<Vector<Vector<TorusValue, W>, B>, T>, N_LV1>& ks) {
     uint64_t h = 0x84222325CBF29CE4ULL;
-    for (int i = 0; i < N_LV1; i += (N_LV1 > 16 ? N_LV1 / 16 : 1))
-        for (int m = 0; m < T; m++) h = mix(h, ks[i][m][B - 1][(i + m) % W].get_raw_value());
+    for (int i = 0; i < N_LV1; i++)
+        for (int m = 0; m < T; m++) h = mix(h, ks[i][m][1 + (i + m) % (B - 1)][(i * 5 + m) % W].get_raw_value());
     return h;
 }
 

@@ -102,8 +102,12 @@ public:
         return p;
     }
 
+    // Forget the device copy of a key that was edited in place (the cache only samples its contents).
+    void invalidate(const EvaluateKey& evaluate_key) { gpu::cache().invalidate(&evaluate_key.bk, &evaluate_key.ks); }
+
     // The device copy of an evaluation key; built on first use and cached on the key's identity.
-    tfhe_amd_ctx* context(const EvaluateKey& evaluate_key) {
+    // The returned handle keeps it alive while the caller evaluates on it.
+    std::shared_ptr<gpu::DeviceKey> context(const EvaluateKey& evaluate_key) {
         return gpu::cache().get(
             params(), &evaluate_key.bk, &evaluate_key.ks,
             gpu::fingerprint(evaluate_key.bk) ^ gpu::fingerprint(evaluate_key.ks),
@@ -115,7 +119,7 @@ public:
         std::vector<uint32_t> fa, fb, out((size_t)N_LV0 + 1);
         gpu::put(fa, a);
         gpu::put(fb, b);
-        gpu::check(tfhe_amd_nand_batch(context(evaluate_key), fa.data(), fb.data(), out.data(), 1), "nand");
+        gpu::check(tfhe_amd_nand_batch(context(evaluate_key)->ctx(), fa.data(), fb.data(), out.data(), 1), "nand");
         return gpu::take_vector<N_LV0 + 1>(out.data());
     }
 
@@ -131,7 +135,12 @@ public:
             gpu::put(fa, a[g]);
             gpu::put(fb, b[g]);
         }
-        gpu::check(tfhe_amd_nand_batch(context(evaluate_key), fa.data(), fb.data(), out.data(), G), "nand_batch");
+        // over every GPU of gpu::devices() when that lists more than one: contiguous blocks of gates
+        const auto key = context(evaluate_key);
+        if (key->multi)
+            gpu::check(tfhe_amd_multi_nand_batch(key->multi, fa.data(), fb.data(), out.data(), G), "nand_batch");
+        else
+            gpu::check(tfhe_amd_nand_batch(key->single, fa.data(), fb.data(), out.data(), G), "nand_batch");
         std::vector<Cipher> res;
         res.reserve(G);
         for (size_t g = 0; g < G; g++) res.push_back(gpu::take_vector<N_LV0 + 1>(out.data() + g * W));
@@ -145,7 +154,8 @@ public:
         std::vector<uint32_t> fa, fb, out((size_t)N_LV0 + 1);
         gpu::put(fa, a);
         gpu::put(fb, b);
-        gpu::check(tfhe_amd_gate_batch(context(evaluate_key), (int)op, fa.data(), fb.data(), out.data(), 1), "gate");
+        gpu::check(tfhe_amd_gate_batch(context(evaluate_key)->ctx(), (int)op, fa.data(), fb.data(), out.data(), 1),
+                   "gate");
         return gpu::take_vector<N_LV0 + 1>(out.data());
     }
 
@@ -158,8 +168,11 @@ public:
             gpu::put(fa, a[g]);
             gpu::put(fb, b[g]);
         }
-        gpu::check(tfhe_amd_gate_batch(context(evaluate_key), (int)op, fa.data(), fb.data(), out.data(), G),
-                   "gate_batch");
+        const auto key = context(evaluate_key);
+        if (key->multi)
+            gpu::check(tfhe_amd_multi_gate_batch(key->multi, (int)op, fa.data(), fb.data(), out.data(), G), "gate_batch");
+        else
+            gpu::check(tfhe_amd_gate_batch(key->single, (int)op, fa.data(), fb.data(), out.data(), G), "gate_batch");
         std::vector<Cipher> res;
         res.reserve(G);
         for (size_t g = 0; g < G; g++) res.push_back(gpu::take_vector<N_LV0 + 1>(out.data() + g * W));
@@ -175,7 +188,8 @@ public:
         gpu::put(fs, sel);
         gpu::put(f1, x1);
         gpu::put(f0, x0);
-        gpu::check(tfhe_amd_mux_batch(context(evaluate_key), fs.data(), f1.data(), f0.data(), out.data(), 1), "mux");
+        gpu::check(tfhe_amd_mux_batch(context(evaluate_key)->ctx(), fs.data(), f1.data(), f0.data(), out.data(), 1),
+                   "mux");
         return gpu::take_vector<N_LV0 + 1>(out.data());
     }
 };

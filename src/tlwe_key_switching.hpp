@@ -50,9 +50,10 @@ public:
         p.K = N_LV1 / p.N;
         p.bg_bit = 8; p.L = 1;  // unused by this call
         p.T = T; p.base_bit = BASE_BIT;
-        tfhe_amd_ctx* ctx = gpu::cache().get(
+        const auto key = gpu::cache().get(
             p, nullptr, &ks, gpu::fingerprint(ks), [] { return std::vector<uint32_t>(); },
             [&] { return gpu::flatten_ks(ks); });
+        tfhe_amd_ctx* ctx = key->ctx();  // `key` keeps the device copy alive for the call
         std::vector<uint32_t> in, out((size_t)N_LV0 + 1);
         gpu::put(in, ba_lv1);
         gpu::check(tfhe_amd_identity_key_switch_batch(ctx, in.data(), out.data(), 1), "identity_key_switch");

@@ -56,7 +56,7 @@ private:
     }
 
     template <int TLWE_N>
-    tfhe_amd_ctx* context_for(const Vector<Ciphertext, TLWE_N>& bk) {
+    std::shared_ptr<gpu::DeviceKey> context_for(const Vector<Ciphertext, TLWE_N>& bk) {
         return gpu::cache().get(
             shape(TLWE_N), &bk, nullptr, gpu::fingerprint(bk), [&] { return gpu::flatten_bk(bk); },
             [] { return std::vector<uint32_t>(); });
@@ -128,7 +128,7 @@ public:
         std::vector<uint32_t> c, tv, acc((size_t)(K + 1) * N);
         gpu::put(c, tlwe_lv0);
         gpu::put(tv, test_vector);
-        gpu::check(tfhe_amd_blind_rotate_batch(context_for(bk), c.data(), tv.data(), acc.data(), 1), "blind_rotate");
+        gpu::check(tfhe_amd_blind_rotate_batch(context_for(bk)->ctx(), c.data(), tv.data(), acc.data(), 1), "blind_rotate");
         return gpu::take_trlwe<N, K + 1>(acc.data());
     }
 
@@ -139,7 +139,7 @@ public:
                                                                   const Vector<Ciphertext, TLWE_N>& bk) {
         std::vector<uint32_t> c, lv1((size_t)N * K + 1);
         gpu::put(c, tlwe_lv0);
-        gpu::check(tfhe_amd_gate_bootstrapping_batch(context_for(bk), c.data(), lv1.data(), 1),
+        gpu::check(tfhe_amd_gate_bootstrapping_batch(context_for(bk)->ctx(), c.data(), lv1.data(), 1),
                    "gate_bootstrapping_tlwe_to_tlwe");
         return gpu::take_vector<N * K + 1>(lv1.data());
     }

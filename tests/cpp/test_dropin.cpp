@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "hom_nand.hpp"
@@ -292,6 +293,69 @@ static void test_hom_nand_other_ring() {  // a ring the reference's HomNAND cann
     }
 }
 
+static void test_concurrent_nand_on_shared_key() {
+    // Eight host threads call nand() on one shared EvaluateKey, as the reference allows (its nand reads
+    // only its arguments, reference src/hom_nand.hpp:74-81).  The first calls race to build the device
+    // copy of the key; every output must equal the one a single thread computes.
+    HomNAND<> h(31);
+    auto sk = h.generate_secret_key();
+    auto ek = h.make_evaluate_key_gpu(sk, 8);
+    constexpr int THREADS = 8, PER = 6;
+    std::vector<HomNAND<>::Cipher> a, b;
+    std::vector<bool> pa, pb;
+    std::mt19937 mt(9);
+    for (int i = 0; i < THREADS * PER; i++) {
+        pa.push_back(mt() & 1);
+        pb.push_back(mt() & 1);
+        a.push_back(h.encrypt(pa.back(), sk));
+        b.push_back(h.encrypt(pb.back(), sk));
+    }
+    std::vector<HomNAND<>::Cipher> out(a.size());
+    std::vector<std::thread> ts;
+    for (int t = 0; t < THREADS; t++)
+        ts.emplace_back([&, t] {
+            for (int i = t * PER; i < (t + 1) * PER; i++) out[i] = h.nand(a[i], b[i], ek);
+        });
+    for (auto& t : ts) t.join();
+    auto serial = h.nand_batch(a, b, ek);
+    for (size_t i = 0; i < a.size(); i++) {
+        CHECK(out[i] == serial[i]);
+        CHECK(h.decrypt(out[i], sk) == !(pa[i] && pb[i]));
+    }
+}
+
+static void test_multi_device_batch() {
+    // nand_batch / gate_batch over a device list: GPU 0 three times when the box has one GPU, so the
+    // contiguous-block split (ragged: 10 gates over 3 entries) is exercised either way.
+    HomNAND<> h(32);
+    auto sk = h.generate_secret_key();
+    auto ek = h.make_evaluate_key_gpu(sk, 9);
+    std::vector<HomNAND<>::Cipher> a, b;
+    std::vector<bool> pa, pb;
+    for (int i = 0; i < 10; i++) {
+        pa.push_back(i & 1);
+        pb.push_back(i & 2);
+        a.push_back(h.encrypt(pa.back(), sk));
+        b.push_back(h.encrypt(pb.back(), sk));
+    }
+    auto one = h.nand_batch(a, b, ek);
+    gpu::devices() = {0, 0, 0};
+    auto many = h.nand_batch(a, b, ek);
+    auto many_or = h.gate_batch(HomNAND<>::Gate::OR, a, b, ek);
+    auto single = h.nand(a[7], b[7], ek);  // single gates run on the first device of the list
+    gpu::devices().clear();
+    for (int i = 0; i < 10; i++) {
+        CHECK(many[i] == one[i]);
+        CHECK(h.decrypt(many[i], sk) == !(pa[i] && pb[i]));
+        CHECK(h.decrypt(many_or[i], sk) == (pa[i] || pb[i]));
+    }
+    CHECK(single == one[7]);
+    // a key edited in place: invalidate() drops the cached device copy
+    ek.bk[0][0][0][0] += TorusValue::from_raw_value(0x01234567u);
+    h.invalidate(ek);
+    CHECK(!(h.nand(a[7], b[7], ek) == one[7]));
+}
+
 static void run_gpu() {
     test_external_product_by_one();
     test_cmux();
@@ -302,6 +366,8 @@ static void run_gpu() {
     test_gpu_keygen();
     test_reference_fft_mode();
     test_hom_nand_other_ring();
+    test_concurrent_nand_on_shared_key();
+    test_multi_device_batch();
     std::puts("gpu group ok");
 }
 

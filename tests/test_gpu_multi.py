@@ -1,0 +1,206 @@
+"""Gates sharded over several GPUs (or over several contexts on one GPU) and several host threads
+on one shared key, against the CPU oracle.  Bit-exact.  The reference allows both usages: a gate
+reads only its two inputs and the read-only keys (reference src/hom_nand.hpp:74-81)."""
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def keys():
+    p = O.params_default()
+    s0, sr, bk, ks = O.keyset(p, seed=4321)
+    return p, s0, bk, ks
+
+
+def _inputs(p, s0, n, seed):
+    rs = np.random.RandomState(seed)
+    bits_a, bits_b = rs.randint(0, 2, n), rs.randint(0, 2, n)
+    r = O.rng(seed)
+    return bits_a, bits_b, O.encrypt_bits(bits_a, s0, p, r), O.encrypt_bits(bits_b, s0, p, r)
+
+
+def _device_list():
+    """Every GPU of the box, and at least three entries (aliased on a small box) so that the split is ragged."""
+    import torch
+
+    n = torch.cuda.device_count()
+    devs = list(range(n))
+    while len(devs) < 3:
+        devs.append(devs[-1])
+    return devs
+
+
+def test_multi_context_ragged_batch_bit_exact(keys):
+    import tfhe_amd
+
+    p, s0, bk, ks = keys
+    devs = _device_list()
+    G = 8 * len(devs) + 5   # not a multiple of the device count
+    bits_a, bits_b, a, b = _inputs(p, s0, G, seed=21)
+    with tfhe_amd.MultiContext(tfhe_amd.params_default(), bk, ks, devs) as m:
+        assert m.device_count() == len(devs)
+        assert all(m.kernel_family(i) == "ntt512" for i in range(len(devs)))
+        bounds = [m.shard(G, i) for i in range(len(devs))]
+        assert bounds[0][0] == 0 and bounds[-1][1] == G
+        assert all(x[1] == y[0] for x, y in zip(bounds, bounds[1:]))
+        assert bounds == [(G * i // len(devs), G * (i + 1) // len(devs)) for i in range(len(devs))]
+        got = m.nand(a, b)
+        got_xor = m.gate("xor", a, b)
+        # fewer gates than devices: some blocks are empty
+        got_small = m.nand(a[:2], b[:2])
+        assert m.nand(a[:0], b[:0]).shape == (0, p.n + 1)
+    octx = O.Context(p, bk, ks)
+    want = octx.nand_batch(a, b)
+    assert np.array_equal(got, want)
+    assert np.array_equal(got_small, want[:2])
+    assert np.array_equal(O.decrypt_bits(got, s0, p), 1 - (bits_a & bits_b))
+    assert np.array_equal(O.decrypt_bits(got_xor, s0, p), bits_a ^ bits_b)
+
+
+def test_multi_context_device_resident_blocks(keys):
+    """tfhe_amd_multi_nand_batch_device: one device-resident block per entry, keys already on the first GPU."""
+    import tfhe_amd
+    import torch
+
+    p, s0, bk, ks = keys
+    devs = _device_list()
+    _, _, a, b = _inputs(p, s0, 4 * len(devs) + 1, seed=22)
+    d0 = torch.device("cuda", devs[0])
+    bk_t = torch.from_numpy(bk.reshape(-1).view(np.int32)).to(d0)
+    ks_t = torch.from_numpy(ks.reshape(-1).view(np.int32)).to(d0)
+    torch.cuda.synchronize()
+    with tfhe_amd.MultiContext(tfhe_amd.params_default(), bk_t, ks_t, devs, keys_on_device=True) as m:
+        ta, tb, to = [], [], []
+        for i, d in enumerate(devs):
+            lo, hi = m.shard(a.shape[0], i)
+            dev = torch.device("cuda", d)
+            ta.append(torch.from_numpy(a[lo:hi].view(np.int32)).to(dev))
+            tb.append(torch.from_numpy(b[lo:hi].view(np.int32)).to(dev))
+            to.append(torch.empty_like(ta[-1]))
+        torch.cuda.synchronize()
+        m.nand_device(ta, tb, to)
+        m.synchronize()
+        got = np.concatenate([t.cpu().numpy().view(np.uint32) for t in to])
+    assert np.array_equal(got, O.Context(p, bk, ks).nand_batch(a, b))
+
+
+def test_eight_host_threads_share_one_context(keys):
+    """Concurrent calls on ONE context from eight host threads (ctypes releases the GIL): batches of
+    different sizes, host-pointer and device-pointer entry points mixed, every word as the oracle's."""
+    import tfhe_amd
+    import torch
+
+    p, s0, bk, ks = keys
+    octx = O.Context(p, bk, ks)
+    sizes = [1, 3, 17, 40, 2, 9, 64, 5]
+    work = [_inputs(p, s0, g, seed=100 + i) for i, g in enumerate(sizes)]
+    want = [octx.nand_batch(w[2], w[3]) for w in work]
+    got, errors = [None] * len(sizes), []
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks) as ctx:
+        start = threading.Barrier(len(sizes))
+
+        def run(i):
+            try:
+                _, _, a, b = work[i]
+                start.wait()
+                for rep in range(3):
+                    if i % 2 == 0:
+                        out = ctx.nand(a, b)
+                    else:
+                        stream = torch.cuda.Stream()
+                        with torch.cuda.stream(stream):
+                            ta = torch.from_numpy(a.view(np.int32)).cuda()
+                            tb = torch.from_numpy(b.view(np.int32)).cuda()
+                            to = torch.empty_like(ta)
+                        ctx.nand_device(ta, tb, to, stream=stream)
+                        stream.synchronize()
+                        out = to.cpu().numpy().view(np.uint32)
+                    if got[i] is not None and not np.array_equal(got[i], out):
+                        raise AssertionError(f"thread {i}: repetition {rep} differs")
+                    got[i] = out
+            except Exception as e:  # surfaced in the main thread
+                errors.append((i, repr(e)))
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(len(sizes))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errors, errors
+    for i in range(len(sizes)):
+        assert np.array_equal(got[i], want[i]), f"thread {i} ({sizes[i]} gates)"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _gloo_worker(rank, world, port, n_gates, q):
+    """One rank of distributed.nand_sharded with Context.nand_device as the evaluator.  Ranks share
+    the box's GPUs round robin (the RCCL run has one GPU per rank; gloo moves host tensors)."""
+    import torch
+    import torch.distributed as dist
+
+    import tfhe_amd
+    from tfhe_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev_index = rank % torch.cuda.device_count()
+        dev = torch.device("cuda", dev_index)
+        p = O.params_default()
+        if rank == 0:
+            s0, sr, bk, ks = O.keyset(p, seed=4321)
+            bits_a, bits_b, a, b = _inputs(p, s0, n_gates, seed=33)
+            a_t, b_t = torch.from_numpy(a.view(np.int32)), torch.from_numpy(b.view(np.int32))
+        else:
+            bk = ks = a_t = b_t = None
+        bk_t, ks_t = D.broadcast_keys(p, bk, ks, src=0)          # host tensors over gloo
+        ctx = tfhe_amd.Context(tfhe_amd.params_default(), bk_t.to(dev), ks_t.to(dev), device=dev_index,
+                               keys_on_device=True)
+
+        def evaluate(x, y):
+            xd, yd = x.to(dev), y.to(dev)
+            out = torch.empty_like(xd)
+            ctx.nand_device(xd, yd, out, stream=torch.cuda.current_stream(dev))
+            torch.cuda.synchronize(dev)
+            return out.cpu()
+
+        full = D.nand_sharded(evaluate, a_t, b_t, n_gates, p.n + 1, src=0)
+        ctx.close()
+        if rank == 0:
+            want = O.Context(p, bk, ks).nand_batch(a, b)
+            ok = np.array_equal(full.numpy().view(np.uint32), want)
+            ok = ok and np.array_equal(O.decrypt_bits(want, s0, p), 1 - (bits_a & bits_b))
+            q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nand_sharded_gloo_world2_on_gpu():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, 11, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(240)
+        assert pr.exitcode == 0
+    assert q.get(timeout=5) is True

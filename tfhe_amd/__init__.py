@@ -4,5 +4,5 @@ This package is a thin ctypes binding of libtfhe_amd.so (C ABI in include/tfhe_a
 used by the tests and the benchmark.  There is no CPU fallback: importing works without
 the library, but every operation raises if it is missing.
 """
-from .binding import (Context, Params, TfheAmdError, cmux, external_product, lib_path, library,  # noqa: F401
+from .binding import (Context, MultiContext, Params, TfheAmdError, cmux, external_product, lib_path, library,  # noqa: F401
                       keygen, load_error, params_default, version)

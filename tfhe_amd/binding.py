@@ -111,6 +111,19 @@ def library():
     lib.tfhe_amd_identity_key_switch_batch_device.argtypes = [vp, vp, vp, sz, vp]
     lib.tfhe_amd_external_product_batch.argtypes = [pp, vp, vp, vp, sz, i32]
     lib.tfhe_amd_cmux_batch.argtypes = [pp, vp, vp, vp, vp, sz, i32]
+    lib.tfhe_amd_multi_ctx_create.argtypes = [pp, vp, vp, C.POINTER(i32), i32, C.c_uint, C.POINTER(vp)]
+    lib.tfhe_amd_multi_ctx_destroy.argtypes = [vp]
+    lib.tfhe_amd_multi_ctx_destroy.restype = None
+    lib.tfhe_amd_multi_ctx_device_count.argtypes = [vp]
+    lib.tfhe_amd_multi_ctx_get.argtypes = [vp, i32]
+    lib.tfhe_amd_multi_ctx_get.restype = vp
+    lib.tfhe_amd_multi_shard.argtypes = [vp, sz, i32, C.POINTER(sz), C.POINTER(sz)]
+    lib.tfhe_amd_multi_shard.restype = None
+    lib.tfhe_amd_multi_nand_batch.argtypes = [vp, vp, vp, vp, sz]
+    lib.tfhe_amd_multi_gate_batch.argtypes = [vp, i32, vp, vp, vp, sz]
+    lib.tfhe_amd_multi_bootstrap_batch.argtypes = [vp, vp, vp, sz]
+    lib.tfhe_amd_multi_nand_batch_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]
+    lib.tfhe_amd_multi_ctx_synchronize.argtypes = [vp]
     lib.tfhe_amd_ctx_kernel_family.argtypes = [vp]
     lib.tfhe_amd_ctx_kernel_family.restype = C.c_char_p
     lib.tfhe_amd_ctx_synchronize.argtypes = [vp]
@@ -419,6 +432,101 @@ class Context:
         br, ks, n = C.c_double(), C.c_double(), C.c_int64()
         _check(library().tfhe_amd_ctx_timing(self._h, C.byref(br), C.byref(ks), C.byref(n)))
         return br.value, ks.value, n.value
+
+
+class MultiContext:
+    """Several GPUs of one node behind one handle (tfhe_amd_multi_ctx): the keys are uploaded once,
+    copied device to device, and a batch is split in contiguous blocks over the device list.
+    devices: GPU ids; an id may appear more than once (each entry gets its own context)."""
+
+    def __init__(self, params, bk, ks, devices, keys_on_device=False, form=None):
+        lib = library()
+        self.params = params
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        flags = (Context.KEYS_ON_DEVICE if keys_on_device else 0)
+        flags |= {None: 0, 'latency': Context.LATENCY_FORM, 'throughput': Context.THROUGHPUT_FORM}[form]
+        bk_words, ks_words = lib.tfhe_amd_bk_words(C.byref(params)), lib.tfhe_amd_ks_words(C.byref(params))
+        if keys_on_device:
+            bk_p, ks_p = _dev_ptr(bk, bk_words), _dev_ptr(ks, ks_words)
+        else:
+            bk, ks = _host_u32(bk).reshape(-1), _host_u32(ks).reshape(-1)
+            if bk.size != bk_words or ks.size != ks_words:
+                raise ValueError("key sizes do not match the parameter set")
+            bk_p, ks_p = bk.ctypes.data_as(C.c_void_p), ks.ctypes.data_as(C.c_void_p)
+        ids = (C.c_int * len(self.devices))(*self.devices)
+        _check(lib.tfhe_amd_multi_ctx_create(C.byref(params), bk_p, ks_p, ids, len(self.devices), flags,
+                                             C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            library().tfhe_amd_multi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_count(self):
+        return library().tfhe_amd_multi_ctx_device_count(self._h)
+
+    def shard(self, n_gates, index):
+        """[begin, end) of the gates entry `index` of the device list evaluates."""
+        lo, hi = C.c_size_t(), C.c_size_t()
+        library().tfhe_amd_multi_shard(self._h, n_gates, index, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def kernel_family(self, index=0):
+        return library().tfhe_amd_ctx_kernel_family(library().tfhe_amd_multi_ctx_get(self._h, index)).decode()
+
+    def nand(self, a, b):
+        """out[g] = NAND(a[g], b[g]) over all devices; host arrays [G, n+1]."""
+        return self.gate("nand", a, b)
+
+    def gate(self, op, a, b):
+        a, b = _host_u32(a), _host_u32(b)
+        if a.shape != b.shape or a.ndim != 2 or a.shape[1] != self.params.n1:
+            raise ValueError("a and b must both be [G, n+1]")
+        out = np.empty_like(a)
+        _check(library().tfhe_amd_multi_gate_batch(self._h, gate_code(op), a.ctypes.data_as(C.c_void_p),
+                                                   b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                   a.shape[0]))
+        return out
+
+    def bootstrap(self, c):
+        c = _host_u32(c)
+        if c.ndim != 2 or c.shape[1] != self.params.n1:
+            raise ValueError("c must be [G, n+1]")
+        out = np.empty_like(c)
+        _check(library().tfhe_amd_multi_bootstrap_batch(self._h, c.ctypes.data_as(C.c_void_p),
+                                                        out.ctypes.data_as(C.c_void_p), c.shape[0]))
+        return out
+
+    def nand_device(self, a, b, out):
+        """a, b, out: one GPU tensor [G_g, n+1] per entry of the device list, each on that entry's
+        GPU.  Asynchronous on every context's own stream; synchronize() waits for all."""
+        n = len(self.devices)
+        if not (len(a) == len(b) == len(out) == n):
+            raise ValueError("one tensor per device expected")
+        VP, SZ = C.c_void_p * n, C.c_size_t * n
+        g = [int(t.shape[0]) for t in a]
+        w = [gi * self.params.n1 for gi in g]
+        pa = VP(*[_dev_ptr(t, wi).value or 0 for t, wi in zip(a, w)])
+        pb = VP(*[_dev_ptr(t, wi).value or 0 for t, wi in zip(b, w)])
+        po = VP(*[_dev_ptr(t, wi).value or 0 for t, wi in zip(out, w)])
+        _check(library().tfhe_amd_multi_nand_batch_device(self._h, pa, pb, po, SZ(*g)))
+        return out
+
+    def synchronize(self):
+        _check(library().tfhe_amd_multi_ctx_synchronize(self._h))
 
 
 def _secret_bytes(params, s_lv0, s_ring):

@@ -5,9 +5,13 @@
 
 #include <cmath>
 #include <cstdio>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -87,6 +91,28 @@ hipError_t scratch_of(int device, uint32_t** out) {
 
 }  // namespace
 
+namespace {
+constexpr int kMaxLanes = 8;
+
+struct Lane {
+    hipStream_t stream = nullptr;  // private stream of the synchronous host-pointer calls
+    // workspace, grown on demand
+    uint32_t* d_c = nullptr;
+    uint32_t* d_lv1 = nullptr;
+    size_t ws_gates = 0;
+    // Calls that use this lane on different streams are ordered through this event: every call
+    // records it behind its last kernel, and a call on another stream waits for it before touching
+    // the workspace.
+    hipEvent_t ws_done = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
+    // staging for the host-pointer entry points
+    uint32_t* d_io = nullptr;
+    size_t io_words = 0;
+    bool busy = false;
+};
+}  // namespace
+
 struct tfhe_amd_ctx {
     tfhe_amd_params p{};
     int device = 0;
@@ -104,22 +130,18 @@ struct tfhe_amd_ctx {
     bool has_bk = false, has_ks = false;
     int form = 0;                  // blind-rotation kernel form: 0 auto, 1 latency, 2 throughput
     hipStream_t stream = nullptr;
-    // workspace, grown on demand
-    uint32_t* d_c = nullptr;
-    uint32_t* d_lv1 = nullptr;
-    size_t ws_gates = 0;
+    // Workspaces.  A call that needs scratch memory (the combined inputs c, the lv1 results, the
+    // staging of host-pointer calls) leases a lane for as long as it enqueues (device-pointer calls) or
+    // runs (host-pointer calls); several host threads may therefore evaluate on one context at once,
+    // as they may call the reference's nand() on one shared EvaluateKey (reference src/hom_nand.hpp:74-81
+    // reads only its arguments).  Lanes are created on demand, at most kMaxLanes of them.
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Lane*> lanes;
     uint32_t* d_scratch = nullptr;  // this device's copy of the static no-allocation workspace
-    // The workspace is shared by all calls on this context.  Calls enqueued on different streams
-    // are ordered through this event: every call records it behind its last kernel, and a call on
-    // another stream waits for it before touching the workspace.
-    hipEvent_t ws_done = nullptr;
-    hipStream_t ws_stream = nullptr;
-    bool ws_used = false;
-    // staging for the host-pointer entry points
-    uint32_t* d_io = nullptr;
-    size_t io_words = 0;
+    std::mutex timing_mu;
     // timing
-    bool timing = false;
+    std::atomic<bool> timing{false};
     std::vector<hipEvent_t> ev;  // kTimingRing * 3
     int ev_head = 0, ev_count = 0;
     double br_ms = 0.0, ks_ms = 0.0;
@@ -285,27 +307,85 @@ size_t n1_of(const tfhe_amd_ctx* c) { return (size_t)c->p.n + 1; }
 size_t lv1_of(const tfhe_amd_ctx* c) { return (size_t)c->p.N * c->p.K + 1; }
 size_t trlwe_of(const tfhe_amd_ctx* c) { return (size_t)(c->p.K + 1) * c->p.N; }
 
-int ensure_workspace(tfhe_amd_ctx* ctx, size_t n_gates) {
-    if (n_gates <= ctx->ws_gates) return TFHE_AMD_OK;
-    if (ctx->d_c) (void)hipFree(ctx->d_c);
-    if (ctx->d_lv1) (void)hipFree(ctx->d_lv1);
-    ctx->d_c = ctx->d_lv1 = nullptr;
-    ctx->ws_gates = 0;
-    HIP_TRY(hipMalloc(&ctx->d_c, n_gates * n1_of(ctx) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&ctx->d_lv1, n_gates * lv1_of(ctx) * sizeof(uint32_t)));
-    ctx->ws_gates = n_gates;
+int ensure_workspace(const tfhe_amd_ctx* ctx, Lane* lane, size_t n_gates) {
+    if (n_gates <= lane->ws_gates) return TFHE_AMD_OK;
+    // hipFree waits for the device, so no kernel still reads the old buffers
+    if (lane->d_c) (void)hipFree(lane->d_c);
+    if (lane->d_lv1) (void)hipFree(lane->d_lv1);
+    lane->d_c = lane->d_lv1 = nullptr;
+    lane->ws_gates = 0;
+    HIP_TRY(hipMalloc(&lane->d_c, n_gates * n1_of(ctx) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&lane->d_lv1, n_gates * lv1_of(ctx) * sizeof(uint32_t)));
+    lane->ws_gates = n_gates;
     return TFHE_AMD_OK;
 }
 
-int ensure_io(tfhe_amd_ctx* ctx, size_t words) {
-    if (words <= ctx->io_words) return TFHE_AMD_OK;
-    if (ctx->d_io) (void)hipFree(ctx->d_io);
-    ctx->d_io = nullptr;
-    ctx->io_words = 0;
-    HIP_TRY(hipMalloc(&ctx->d_io, words * sizeof(uint32_t)));
-    ctx->io_words = words;
+int ensure_io(Lane* lane, size_t words) {
+    if (words <= lane->io_words) return TFHE_AMD_OK;
+    if (lane->d_io) (void)hipFree(lane->d_io);
+    lane->d_io = nullptr;
+    lane->io_words = 0;
+    HIP_TRY(hipMalloc(&lane->d_io, words * sizeof(uint32_t)));
+    lane->io_words = words;
     return TFHE_AMD_OK;
 }
+
+void lane_free(Lane* lane) {
+    if (!lane) return;
+    if (lane->stream) (void)hipStreamSynchronize(lane->stream);
+    if (lane->ws_done) (void)hipEventDestroy(lane->ws_done);
+    void* bufs[] = {lane->d_c, lane->d_lv1, lane->d_io};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (lane->stream) (void)hipStreamDestroy(lane->stream);
+    delete lane;
+}
+
+// Exclusive use of one lane of a context until the lease goes out of scope.  The context's device
+// must be current.  Prefers a free lane whose workspace was last used on `prefer` (no cross-stream
+// wait needed), then any free lane, then a new one; with kMaxLanes lanes all busy it waits.
+struct LaneLease {
+    tfhe_amd_ctx* ctx;
+    Lane* lane = nullptr;
+    int rc = TFHE_AMD_OK;
+    LaneLease(tfhe_amd_ctx* c, hipStream_t prefer) : ctx(c) {
+        std::unique_lock<std::mutex> lock(ctx->mu);
+        for (;;) {
+            Lane* free_lane = nullptr;
+            for (Lane* l : ctx->lanes) {
+                if (l->busy) continue;
+                if (!free_lane || (l->ws_used && l->ws_stream == prefer)) free_lane = l;
+                if (l->ws_used && l->ws_stream == prefer) break;
+            }
+            if (free_lane) { lane = free_lane; break; }
+            if ((int)ctx->lanes.size() < kMaxLanes) {
+                Lane* l = new (std::nothrow) Lane();
+                if (!l) { rc = fail(TFHE_AMD_ERR_MEMORY, "host allocation failed"); return; }
+                hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&l->ws_done, hipEventDisableTiming);
+                if (e != hipSuccess) {
+                    lane_free(l);
+                    rc = fail(hip_code(e), std::string("creating a workspace lane: ") + hipGetErrorString(e));
+                    return;
+                }
+                ctx->lanes.push_back(l);
+                lane = l;
+                break;
+            }
+            ctx->cv.wait(lock);
+        }
+        lane->busy = true;
+    }
+    ~LaneLease() {
+        if (!lane) return;
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            lane->busy = false;
+        }
+        ctx->cv.notify_one();
+    }
+    LaneLease(const LaneLease&) = delete;
+    LaneLease& operator=(const LaneLease&) = delete;
+};
 
 int drain_timing(tfhe_amd_ctx* ctx, int keep) {
     while (ctx->ev_count > keep) {
@@ -371,12 +451,14 @@ int run_key_switch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t
 // bootstrap + key switch on device data, with optional event timing.  The last n_mux of the
 // n_gates gates are MUXes: c holds n_gates + n_mux rows, and the lv1 result of row n_gates + j is
 // added (plus 1/8) to that of row n_gates - n_mux + j before the key switch.
-int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s,
+int run_bootstrap(tfhe_amd_ctx* ctx, Lane* lane, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s,
                   size_t n_mux = 0, uint32_t* lv1_ws = nullptr) {
-    uint32_t* const d_lv1 = lv1_ws ? lv1_ws : ctx->d_lv1;
+    uint32_t* const d_lv1 = lv1_ws ? lv1_ws : lane->d_lv1;
     hipEvent_t* e = nullptr;
+    std::unique_lock<std::mutex> tlock(ctx->timing_mu, std::defer_lock);
     // (the combination kernels that fill `c` ran on `s` already, after workspace_acquire)
     if (ctx->timing && !lv1_ws) {  // draining the event ring may block: not on the no-allocation path
+        tlock.lock();  // one timed call at a time records into the ring
         if (ctx->ev_count == kTimingRing) {
             int rc = drain_timing(ctx, kTimingRing - 1);
             if (rc) return rc;
@@ -397,48 +479,96 @@ int run_bootstrap(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_
         ctx->ev_count++;
     }
     if (lv1_ws) return TFHE_AMD_OK;  // the static workspace is not ordered through the context
-    HIP_TRY(hipEventRecord(ctx->ws_done, s));
-    ctx->ws_stream = s;
-    ctx->ws_used = true;
+    HIP_TRY(hipEventRecord(lane->ws_done, s));
+    lane->ws_stream = s;
+    lane->ws_used = true;
     return TFHE_AMD_OK;
 }
 
-// Orders a call on stream `s` behind the previous user of the workspace when that one ran on
-// another stream, and grows the workspace (hipFree waits for the device, so no kernel still reads
-// the old buffers).
-int workspace_acquire(tfhe_amd_ctx* ctx, size_t n_rows, hipStream_t s) {
-    if (!ctx->ws_done) HIP_TRY(hipEventCreateWithFlags(&ctx->ws_done, hipEventDisableTiming));
-    if (ctx->ws_used && ctx->ws_stream != s) HIP_TRY(hipStreamWaitEvent(s, ctx->ws_done, 0));
-    return ensure_workspace(ctx, n_rows);
+// Orders a call on stream `s` behind the previous user of the lane's workspace when that one ran
+// on another stream, and grows the workspace.
+int workspace_acquire(const tfhe_amd_ctx* ctx, Lane* lane, size_t n_rows, hipStream_t s) {
+    if (lane->ws_used && lane->ws_stream != s) HIP_TRY(hipStreamWaitEvent(s, lane->ws_done, 0));
+    return ensure_workspace(ctx, lane, n_rows);
 }
 
 int check_gate_code(int op) {
     return (op >= 0 && op < TFHE_AMD_GATE_COUNT) ? TFHE_AMD_OK : fail(TFHE_AMD_ERR_ARGUMENT, "unknown gate code");
 }
 
-// Host-pointer wrapper: copies `n_in` input arrays to the staging buffer, runs `body` on the
-// device copies, copies one output array back.  in_words[k] / out_words are per-array sizes.
+// Host-pointer wrapper: leases a lane, copies `n_in` input arrays to its staging buffer, runs `body`
+// on the device copies on the lane's private stream, copies one output array back and waits.
+// in_words[k] / out_words are per-array sizes.
 template <typename Body>
 int with_staging(tfhe_amd_ctx* ctx, const uint32_t* const* in, const size_t* in_words, int n_in, uint32_t* out,
                  size_t out_words, Body body) {
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
+    LaneLease lease(ctx, nullptr);
+    if (lease.rc) return lease.rc;
+    Lane* lane = lease.lane;
     size_t total = out_words;
     for (int k = 0; k < n_in; k++) total += in_words[k];
-    int rc = ensure_io(ctx, total);
+    int rc = ensure_io(lane, total);
     if (rc) return rc;
     const uint32_t* dev_in[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t* cur = ctx->d_io;
+    uint32_t* cur = lane->d_io;
     for (int k = 0; k < n_in; k++) {
         if (in[k]) {
-            HIP_TRY(hipMemcpyAsync(cur, in[k], in_words[k] * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(cur, in[k], in_words[k] * sizeof(uint32_t), hipMemcpyHostToDevice, lane->stream));
             dev_in[k] = cur;
         }
         cur += in_words[k];
     }
-    rc = body(dev_in, cur);
+    rc = body(lane, dev_in, cur);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, cur, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, cur, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, lane->stream));
+    HIP_TRY(hipStreamSynchronize(lane->stream));
     return TFHE_AMD_OK;
+}
+
+// ---- evaluation on device data with a leased lane; `s` is the stream everything is enqueued on ----
+
+int bootstrap_on(tfhe_amd_ctx* ctx, Lane* lane, const uint32_t* c, uint32_t* out, size_t n_gates, hipStream_t s) {
+    int rc = workspace_acquire(ctx, lane, n_gates, s);
+    if (rc) return rc;
+    return run_bootstrap(ctx, lane, c, out, n_gates, s);
+}
+
+// op < 0: NAND through its own kernel; otherwise gate code `op`, or per-gate codes `ops` when not null
+int gate_on(tfhe_amd_ctx* ctx, Lane* lane, const uint8_t* ops, int op, const uint32_t* a, const uint32_t* b,
+            uint32_t* out, size_t n_gates, hipStream_t s) {
+    int rc = workspace_acquire(ctx, lane, n_gates, s);
+    if (rc) return rc;
+    if (op < 0) HIP_TRY(launch_nand_combine(lane->d_c, a, b, n_gates, ctx->p.n + 1, s));
+    else        HIP_TRY(launch_gate_combine(lane->d_c, a, b, ops, op, n_gates, ctx->p.n + 1, s));
+    return run_bootstrap(ctx, lane, lane->d_c, out, n_gates, s);
+}
+
+int level_on(tfhe_amd_ctx* ctx, Lane* lane, const uint8_t* ops, const uint32_t* a, const uint32_t* b,
+             const uint32_t* x0, uint32_t* out, size_t n_gates, size_t n_mux, hipStream_t s) {
+    const size_t n_two = n_gates - n_mux;
+    int rc = workspace_acquire(ctx, lane, n_gates + n_mux, s);
+    if (rc) return rc;
+    const size_t n1 = n1_of(ctx);
+    uint32_t* d_c = lane->d_c;
+    HIP_TRY(launch_gate_combine(d_c, a, b, ops, 0, n_two, (int)n1, s));
+    HIP_TRY(launch_gate_combine(d_c + n_two * n1, a + n_two * n1, b + n_two * n1, nullptr, TFHE_AMD_GATE_AND, n_mux,
+                                (int)n1, s));
+    HIP_TRY(launch_gate_combine(d_c + n_gates * n1, a + n_two * n1, x0, nullptr, TFHE_AMD_GATE_ANDNY, n_mux, (int)n1,
+                                s));
+    return run_bootstrap(ctx, lane, d_c, out, n_gates, s, n_mux);
+}
+
+// device-pointer entry points that need a workspace: lease a lane while enqueueing on the caller's stream
+template <typename Body>
+int with_lane(tfhe_amd_ctx* ctx, void* stream, Body body) {
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = pick_stream(ctx, stream);
+    LaneLease lease(ctx, s);
+    if (lease.rc) return lease.rc;
+    return body(lease.lane, s);
 }
 
 int external_product_common(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
@@ -683,9 +813,9 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (Lane* l : ctx->lanes) lane_free(l);
     for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
-    if (ctx->ws_done) (void)hipEventDestroy(ctx->ws_done);
-    void* bufs[] = {ctx->d_tw, ctx->d_bk_ntt, ctx->d_bk_raw, ctx->d_spec, ctx->d_ks, ctx->d_c, ctx->d_lv1, ctx->d_io};
+    void* bufs[] = {ctx->d_tw, ctx->d_bk_ntt, ctx->d_bk_raw, ctx->d_spec, ctx->d_ks};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -698,10 +828,7 @@ int tfhe_amd_bootstrap_batch_device(tfhe_amd_ctx* ctx, const uint32_t* c, uint32
     int rc = check_batch(ctx, n_gates, c && out);
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
-    DeviceGuard guard(ctx->device);
-    hipStream_t s = pick_stream(ctx, stream);
-    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
-    return run_bootstrap(ctx, c, out, n_gates, s);
+    return with_lane(ctx, stream, [&](Lane* lane, hipStream_t s) { return bootstrap_on(ctx, lane, c, out, n_gates, s); });
 }
 
 int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
@@ -709,11 +836,8 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
     int rc = check_batch(ctx, n_gates, a && b && out);
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
-    DeviceGuard guard(ctx->device);
-    hipStream_t s = pick_stream(ctx, stream);
-    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
-    HIP_TRY(launch_nand_combine(ctx->d_c, a, b, n_gates, ctx->p.n + 1, s));
-    return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
+    return with_lane(ctx, stream,
+                     [&](Lane* lane, hipStream_t s) { return gate_on(ctx, lane, nullptr, -1, a, b, out, n_gates, s); });
 }
 
 int tfhe_amd_nand_batch_device_noalloc(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,
@@ -732,7 +856,7 @@ int tfhe_amd_nand_batch_device_noalloc(tfhe_amd_ctx* ctx, const uint32_t* a, con
     uint32_t* const d_c = ctx->d_scratch;
     uint32_t* const d_lv1 = ctx->d_scratch + n_gates * n1;
     HIP_TRY(launch_nand_combine(d_c, a, b, n_gates, (int)n1, s));
-    return run_bootstrap(ctx, d_c, out, n_gates, s, 0, d_lv1);
+    return run_bootstrap(ctx, nullptr, d_c, out, n_gates, s, 0, d_lv1);
 }
 
 int tfhe_amd_gate_batch_device(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
@@ -740,11 +864,8 @@ int tfhe_amd_gate_batch_device(tfhe_amd_ctx* ctx, int op, const uint32_t* a, con
     int rc = check_batch(ctx, n_gates, a && b && out);
     if (rc || (rc = check_gate_code(op)) || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
-    DeviceGuard guard(ctx->device);
-    hipStream_t s = pick_stream(ctx, stream);
-    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
-    HIP_TRY(launch_gate_combine(ctx->d_c, a, b, nullptr, op, n_gates, ctx->p.n + 1, s));
-    return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
+    return with_lane(ctx, stream,
+                     [&](Lane* lane, hipStream_t s) { return gate_on(ctx, lane, nullptr, op, a, b, out, n_gates, s); });
 }
 
 int tfhe_amd_gates_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uint32_t* a, const uint32_t* b,
@@ -752,11 +873,8 @@ int tfhe_amd_gates_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uin
     int rc = check_batch(ctx, n_gates, ops && a && b && out);
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
-    DeviceGuard guard(ctx->device);
-    hipStream_t s = pick_stream(ctx, stream);
-    if ((rc = workspace_acquire(ctx, n_gates, s))) return rc;
-    HIP_TRY(launch_gate_combine(ctx->d_c, a, b, ops, 0, n_gates, ctx->p.n + 1, s));
-    return run_bootstrap(ctx, ctx->d_c, out, n_gates, s);
+    return with_lane(ctx, stream,
+                     [&](Lane* lane, hipStream_t s) { return gate_on(ctx, lane, ops, 0, a, b, out, n_gates, s); });
 }
 
 int tfhe_amd_not_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, uint32_t* out, size_t n_gates, void* stream) {
@@ -774,16 +892,9 @@ int tfhe_amd_level_batch_device(tfhe_amd_ctx* ctx, const uint8_t* ops, const uin
     int rc = check_batch(ctx, n_gates + n_mux, a && b && out && (n_two == 0 || ops) && (n_mux == 0 || x0));
     if (rc || n_gates == 0) return rc;
     if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
-    DeviceGuard guard(ctx->device);
-    hipStream_t s = pick_stream(ctx, stream);
-    if ((rc = workspace_acquire(ctx, n_gates + n_mux, s))) return rc;
-    const size_t n1 = n1_of(ctx);
-    HIP_TRY(launch_gate_combine(ctx->d_c, a, b, ops, 0, n_two, (int)n1, s));
-    HIP_TRY(launch_gate_combine(ctx->d_c + n_two * n1, a + n_two * n1, b + n_two * n1, nullptr, TFHE_AMD_GATE_AND,
-                                n_mux, (int)n1, s));
-    HIP_TRY(launch_gate_combine(ctx->d_c + n_gates * n1, a + n_two * n1, x0, nullptr, TFHE_AMD_GATE_ANDNY, n_mux,
-                                (int)n1, s));
-    return run_bootstrap(ctx, ctx->d_c, out, n_gates, s, n_mux);
+    return with_lane(ctx, stream, [&](Lane* lane, hipStream_t s) {
+        return level_on(ctx, lane, ops, a, b, x0, out, n_gates, n_mux, s);
+    });
 }
 
 int tfhe_amd_mux_batch_device(tfhe_amd_ctx* ctx, const uint32_t* sel, const uint32_t* x1, const uint32_t* x0,
@@ -818,17 +929,17 @@ int tfhe_amd_identity_key_switch_batch_device(tfhe_amd_ctx* ctx, const uint32_t*
     return run_key_switch(ctx, lv1, out, n_gates, pick_stream(ctx, stream));
 }
 
-// ---- host-pointer entry points --------------------------------------------------------------
+// ---- host-pointer entry points (synchronous; each call runs on a lane's private stream) -----------
 
 int tfhe_amd_nand_batch(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n_gates) {
     int rc = check_batch(ctx, n_gates, a && b && out);
     if (rc || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     const size_t w = n_gates * n1_of(ctx);
     const uint32_t* in[2] = {a, b};
     const size_t iw[2] = {w, w};
-    return with_staging(ctx, in, iw, 2, out, w, [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_nand_batch_device(ctx, d[0], d[1], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 2, out, w, [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        return gate_on(ctx, lane, nullptr, -1, d[0], d[1], o, n_gates, lane->stream);
     });
 }
 
@@ -836,24 +947,24 @@ int tfhe_amd_gate_batch(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint
                         size_t n_gates) {
     int rc = check_batch(ctx, n_gates, a && b && out);
     if (rc || (rc = check_gate_code(op)) || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     const size_t w = n_gates * n1_of(ctx);
     const uint32_t* in[2] = {a, b};
     const size_t iw[2] = {w, w};
-    return with_staging(ctx, in, iw, 2, out, w, [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_gate_batch_device(ctx, op, d[0], d[1], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 2, out, w, [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        return gate_on(ctx, lane, nullptr, op, d[0], d[1], o, n_gates, lane->stream);
     });
 }
 
 int tfhe_amd_not_batch(tfhe_amd_ctx* ctx, const uint32_t* a, uint32_t* out, size_t n_gates) {
     int rc = check_batch(ctx, n_gates, a && out);
     if (rc || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
     const size_t w = n_gates * n1_of(ctx);
     const uint32_t* in[1] = {a};
     const size_t iw[1] = {w};
-    return with_staging(ctx, in, iw, 1, out, w, [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_not_batch_device(ctx, d[0], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 1, out, w, [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        HIP_TRY(launch_negate(o, d[0], w, lane->stream));
+        return (int)TFHE_AMD_OK;
     });
 }
 
@@ -861,35 +972,35 @@ int tfhe_amd_mux_batch(tfhe_amd_ctx* ctx, const uint32_t* sel, const uint32_t* x
                        size_t n_gates) {
     int rc = check_batch(ctx, 2 * n_gates, sel && x1 && x0 && out);
     if (rc || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     const size_t w = n_gates * n1_of(ctx);
     const uint32_t* in[3] = {sel, x1, x0};
     const size_t iw[3] = {w, w, w};
-    return with_staging(ctx, in, iw, 3, out, w, [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_mux_batch_device(ctx, d[0], d[1], d[2], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 3, out, w, [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        return level_on(ctx, lane, nullptr, d[0], d[1], d[2], o, n_gates, n_gates, lane->stream);
     });
 }
 
 int tfhe_amd_bootstrap_batch(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* out, size_t n_gates) {
     int rc = check_batch(ctx, n_gates, c && out);
     if (rc || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
+    if ((rc = need_bk(ctx)) || (rc = need_ks(ctx))) return rc;
     const size_t w = n_gates * n1_of(ctx);
     const uint32_t* in[1] = {c};
     const size_t iw[1] = {w};
-    return with_staging(ctx, in, iw, 1, out, w, [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_bootstrap_batch_device(ctx, d[0], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 1, out, w, [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        return bootstrap_on(ctx, lane, d[0], o, n_gates, lane->stream);
     });
 }
 
 int tfhe_amd_gate_bootstrapping_batch(tfhe_amd_ctx* ctx, const uint32_t* c, uint32_t* lv1, size_t n_gates) {
     int rc = check_batch(ctx, n_gates, c && lv1);
     if (rc || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
+    if ((rc = need_bk(ctx))) return rc;
     const uint32_t* in[1] = {c};
     const size_t iw[1] = {n_gates * n1_of(ctx)};
-    return with_staging(ctx, in, iw, 1, lv1, n_gates * lv1_of(ctx), [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_gate_bootstrapping_batch_device(ctx, d[0], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 1, lv1, n_gates * lv1_of(ctx), [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        return run_blind_rotate(ctx, d[0], nullptr, o, n_gates, 1, lane->stream);
     });
 }
 
@@ -897,22 +1008,22 @@ int tfhe_amd_blind_rotate_batch(tfhe_amd_ctx* ctx, const uint32_t* c, const uint
                                 size_t n_gates) {
     int rc = check_batch(ctx, n_gates, c && acc);
     if (rc || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
+    if ((rc = need_bk(ctx))) return rc;
     const uint32_t* in[2] = {c, test_vector};
     const size_t iw[2] = {n_gates * n1_of(ctx), trlwe_of(ctx)};
-    return with_staging(ctx, in, iw, 2, acc, n_gates * trlwe_of(ctx), [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_blind_rotate_batch_device(ctx, d[0], d[1], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 2, acc, n_gates * trlwe_of(ctx), [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        return run_blind_rotate(ctx, d[0], d[1], o, n_gates, 0, lane->stream);
     });
 }
 
 int tfhe_amd_identity_key_switch_batch(tfhe_amd_ctx* ctx, const uint32_t* lv1, uint32_t* out, size_t n_gates) {
     int rc = check_batch(ctx, n_gates, lv1 && out);
     if (rc || n_gates == 0) return rc;
-    DeviceGuard guard(ctx->device);
+    if ((rc = need_ks(ctx))) return rc;
     const uint32_t* in[1] = {lv1};
     const size_t iw[1] = {n_gates * lv1_of(ctx)};
-    return with_staging(ctx, in, iw, 1, out, n_gates * n1_of(ctx), [&](const uint32_t* const* d, uint32_t* o) {
-        return tfhe_amd_identity_key_switch_batch_device(ctx, d[0], o, n_gates, nullptr);
+    return with_staging(ctx, in, iw, 1, out, n_gates * n1_of(ctx), [&](Lane* lane, const uint32_t* const* d, uint32_t* o) {
+        return run_key_switch(ctx, d[0], o, n_gates, lane->stream);
     });
 }
 
@@ -949,6 +1060,7 @@ int tfhe_amd_ctx_synchronize(tfhe_amd_ctx* ctx) {
 int tfhe_amd_ctx_enable_timing(tfhe_amd_ctx* ctx, int enable) {
     if (!ctx) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
     DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> tlock(ctx->timing_mu);
     if (enable && ctx->ev.empty()) {
         ctx->ev.assign((size_t)kTimingRing * 3, nullptr);
         for (hipEvent_t& e : ctx->ev) HIP_TRY(hipEventCreate(&e));
@@ -964,6 +1076,7 @@ int tfhe_amd_ctx_enable_timing(tfhe_amd_ctx* ctx, int enable) {
 int tfhe_amd_ctx_timing(tfhe_amd_ctx* ctx, double* blind_rotate_ms, double* key_switch_ms, int64_t* calls) {
     if (!ctx) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
     DeviceGuard guard(ctx->device);
+    std::lock_guard<std::mutex> tlock(ctx->timing_mu);
     int rc = drain_timing(ctx, 0);
     if (rc) return rc;
     if (blind_rotate_ms) *blind_rotate_ms = ctx->br_ms;
@@ -974,7 +1087,181 @@ int tfhe_amd_ctx_timing(tfhe_amd_ctx* ctx, double* blind_rotate_ms, double* key_
     return TFHE_AMD_OK;
 }
 
+// ---- several GPUs behind one handle ------------------------------------------------------------
+
+}  // extern "C"
+
+struct tfhe_amd_multi_ctx {
+    tfhe_amd_params p{};
+    std::vector<tfhe_amd_ctx*> ctx;  // one per entry of the device list (a device may appear twice)
+};
+
+namespace {
+
+// contiguous block split: device g of P owns gates [g G / P, (g + 1) G / P)
+size_t block_begin(size_t n_gates, size_t g, size_t parts) { return n_gates * g / parts; }
+
+// Runs body(g) for every device of the list on a host thread of its own and returns the first
+// failure (with its message as this thread's last error).
+template <typename Body>
+int on_all_devices(tfhe_amd_multi_ctx* m, Body body) {
+    const size_t P = m->ctx.size();
+    std::vector<int> rc(P, TFHE_AMD_OK);
+    std::vector<std::string> msg(P);
+    auto run = [&](size_t g) {
+        rc[g] = body(g);
+        if (rc[g]) msg[g] = g_last_error;  // thread-local in the worker
+    };
+    std::vector<std::thread> workers;
+    workers.reserve(P);
+    for (size_t g = 1; g < P; g++) workers.emplace_back(run, g);
+    run(0);
+    for (std::thread& t : workers) t.join();
+    for (size_t g = 0; g < P; g++)
+        if (rc[g]) return fail(rc[g], "device " + std::to_string(m->ctx[g]->device) + ": " + msg[g]);
+    return TFHE_AMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfhe_amd_multi_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint32_t* ks, const int* device_ids,
+                              int n_devices, unsigned flags, tfhe_amd_multi_ctx** out) {
+    if (!out) return fail(TFHE_AMD_ERR_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
+    if (!device_ids || n_devices < 1 || n_devices > kMaxDevices)
+        return fail(TFHE_AMD_ERR_ARGUMENT, "device list is empty or too long");
+    if (!bk && !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "both key pointers are null");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    for (int g = 0; g < n_devices; g++)
+        if (device_ids[g] < 0 || device_ids[g] >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
+    tfhe_amd_multi_ctx* m = new (std::nothrow) tfhe_amd_multi_ctx();
+    if (!m) return fail(TFHE_AMD_ERR_MEMORY, "host allocation failed");
+    m->p = *p;
+    m->ctx.assign((size_t)n_devices, nullptr);
+    auto bail = [&](int rc) {
+        const std::string msg = g_last_error;
+        tfhe_amd_multi_ctx_destroy(m);
+        return fail(rc, msg);
+    };
+    // The raw keys reach the first device of the list once (from the host, or they are there already
+    // with TFHE_AMD_CTX_KEYS_ON_DEVICE); the other devices get theirs by device-to-device copies over
+    // xGMI, and every device transforms its own copy: the raw keys are half the size of the
+    // transformed ones.
+    const int dev0 = device_ids[0];
+    const size_t bk_bytes = tfhe_amd_bk_words(p) * sizeof(uint32_t), ks_bytes = tfhe_amd_ks_words(p) * sizeof(uint32_t);
+    const bool on_device = (flags & TFHE_AMD_CTX_KEYS_ON_DEVICE) != 0;
+    DevBuf raw_bk, raw_ks;  // on dev0
+    const uint32_t* d_bk = bk;
+    const uint32_t* d_ks = ks;
+    if (!on_device && n_devices > 1) {
+        DeviceGuard guard(dev0);
+        if (!guard.ok) return bail(fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed"));
+        hipError_t e = hipSuccess;
+        if (bk && (e = raw_bk.alloc(bk_bytes)) == hipSuccess) e = hipMemcpy(raw_bk.p, bk, bk_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess && ks && (e = raw_ks.alloc(ks_bytes)) == hipSuccess)
+            e = hipMemcpy(raw_ks.p, ks, ks_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(fail(hip_code(e), std::string("uploading the keys: ") + hipGetErrorString(e)));
+        d_bk = bk ? raw_bk.as<uint32_t>() : nullptr;
+        d_ks = ks ? raw_ks.as<uint32_t>() : nullptr;
+    }
+    const unsigned dev_flags = flags | (n_devices > 1 ? (unsigned)TFHE_AMD_CTX_KEYS_ON_DEVICE : 0u);
+    const int rc = on_all_devices(m, [&](size_t g) -> int {
+        const int dev = device_ids[g];
+        if (dev == dev0 || n_devices == 1) return tfhe_amd_ctx_create(p, d_bk, d_ks, dev, dev_flags, &m->ctx[g]);
+        DeviceGuard guard(dev);
+        if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
+        DevBuf peer_bk, peer_ks;
+        if (d_bk) {
+            HIP_TRY(peer_bk.alloc(bk_bytes));
+            HIP_TRY(hipMemcpyPeer(peer_bk.p, dev, d_bk, dev0, bk_bytes));
+        }
+        if (d_ks) {
+            HIP_TRY(peer_ks.alloc(ks_bytes));
+            HIP_TRY(hipMemcpyPeer(peer_ks.p, dev, d_ks, dev0, ks_bytes));
+        }
+        return tfhe_amd_ctx_create(p, d_bk ? peer_bk.as<uint32_t>() : nullptr, d_ks ? peer_ks.as<uint32_t>() : nullptr, dev,
+                                   dev_flags, &m->ctx[g]);
+    });
+    if (rc) return bail(rc);
+    *out = m;
+    return TFHE_AMD_OK;
+}
+
+void tfhe_amd_multi_ctx_destroy(tfhe_amd_multi_ctx* m) {
+    if (!m) return;
+    for (tfhe_amd_ctx* c : m->ctx) tfhe_amd_ctx_destroy(c);
+    delete m;
+}
+
+int tfhe_amd_multi_ctx_device_count(const tfhe_amd_multi_ctx* m) { return m ? (int)m->ctx.size() : 0; }
+
+tfhe_amd_ctx* tfhe_amd_multi_ctx_get(tfhe_amd_multi_ctx* m, int index) {
+    return (m && index >= 0 && index < (int)m->ctx.size()) ? m->ctx[(size_t)index] : nullptr;
+}
+
+void tfhe_amd_multi_shard(const tfhe_amd_multi_ctx* m, size_t n_gates, int index, size_t* begin, size_t* end) {
+    const size_t P = m ? m->ctx.size() : 1, g = (size_t)(index < 0 ? 0 : index);
+    if (begin) *begin = block_begin(n_gates, g < P ? g : P, P);
+    if (end) *end = block_begin(n_gates, g + 1 < P ? g + 1 : P, P);
+}
+
+int tfhe_amd_multi_gate_batch(tfhe_amd_multi_ctx* m, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                              size_t n_gates) {
+    if (!m) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
+    if (n_gates && !(a && b && out)) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
+    int rc = check_gate_code(op);
+    if (rc || n_gates == 0) return rc;
+    const size_t P = m->ctx.size(), n1 = (size_t)m->p.n + 1;
+    return on_all_devices(m, [&](size_t g) -> int {
+        const size_t lo = block_begin(n_gates, g, P), hi = block_begin(n_gates, g + 1, P);
+        if (hi == lo) return TFHE_AMD_OK;
+        return tfhe_amd_gate_batch(m->ctx[g], op, a + lo * n1, b + lo * n1, out + lo * n1, hi - lo);
+    });
+}
+
+int tfhe_amd_multi_nand_batch(tfhe_amd_multi_ctx* m, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                              size_t n_gates) {
+    return tfhe_amd_multi_gate_batch(m, TFHE_AMD_GATE_NAND, a, b, out, n_gates);
+}
+
+int tfhe_amd_multi_bootstrap_batch(tfhe_amd_multi_ctx* m, const uint32_t* c, uint32_t* out, size_t n_gates) {
+    if (!m) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
+    if (n_gates && !(c && out)) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
+    if (n_gates == 0) return TFHE_AMD_OK;
+    const size_t P = m->ctx.size(), n1 = (size_t)m->p.n + 1;
+    return on_all_devices(m, [&](size_t g) -> int {
+        const size_t lo = block_begin(n_gates, g, P), hi = block_begin(n_gates, g + 1, P);
+        if (hi == lo) return TFHE_AMD_OK;
+        return tfhe_amd_bootstrap_batch(m->ctx[g], c + lo * n1, out + lo * n1, hi - lo);
+    });
+}
+
+int tfhe_amd_multi_nand_batch_device(tfhe_amd_multi_ctx* m, const uint32_t* const* a, const uint32_t* const* b,
+                                     uint32_t* const* out, const size_t* n_gates) {
+    if (!m) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
+    if (!a || !b || !out || !n_gates) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
+    // enqueueing is quick: one host thread walks the devices, the GPUs run side by side
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        const int rc = tfhe_amd_nand_batch_device(m->ctx[g], a[g], b[g], out[g], n_gates[g], nullptr);
+        if (rc) return rc;
+    }
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_multi_ctx_synchronize(tfhe_amd_multi_ctx* m) {
+    if (!m) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
+    for (tfhe_amd_ctx* c : m->ctx) {
+        const int rc = tfhe_amd_ctx_synchronize(c);
+        if (rc) return rc;
+    }
+    return TFHE_AMD_OK;
+}
+
 const char* tfhe_amd_last_error(void) { return g_last_error.c_str(); }
-const char* tfhe_amd_version(void) { return "0.3.0"; }
+const char* tfhe_amd_version(void) { return "0.4.0"; }
 
 }  // extern "C"
