@@ -38,6 +38,8 @@ F64_INSTR_PER_GATE = BUTTERFLIES_PER_GATE * 8 + MACS_PER_GATE * 7
 # FP64 vector peak of MI355X: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz (= 78.6 TFLOP/s as FMAs)
 F64_LANE_INSTR_PEAK = 256 * 4 * 16 * 2.4e9
 IO_BYTES_PER_GATE = 3 * 637 * 4
+# counter summary of the dominant kernel quoted in roofline.traffic (tools/pmc_passes.sh + tools/pmc_summarize.py)
+PMC_SUMMARY = "r02_pmc_summary.json"
 
 
 def cpu_baseline(params, sample_gates, threads):
@@ -111,24 +113,36 @@ def main():
     p = tfhe_amd.params_default()
     n1, G = p.n + 1, args.gates_per_gpu
 
-    # synthetic keys: uniformly random words of the right shape (the work is data-independent)
+    # A real key set (random binary secrets, evaluation keys generated on rank 0's GPU with the
+    # reference's noise parameters, src/tlwe.hpp:13 and src/trlwe.hpp:12) and real encryptions, so
+    # that every rank can check what it computed by decrypting it.  Synthetic: nothing is loaded.
+    alpha_lv0, alpha_lv1 = 9.25119974676756e-5, 2.0 ** -25
     bk_words, ks_words = int(np.prod(p.bk_shape())), int(np.prod(p.ks_shape()))
+    rs = np.random.RandomState(2026)
+    s_lv0 = rs.randint(0, 2, p.n).astype(np.uint8)      # same secret on every rank (same seed)
+    s_ring = rs.randint(0, 2, (p.K, p.N)).astype(np.uint8)
     if rank == 0:
-        rs = np.random.RandomState(2026)
-        bk = torch.from_numpy(rs.randint(-2**31, 2**31, size=bk_words, dtype=np.int64).astype(np.int32)).to(bcast_dev)
-        ks = torch.from_numpy(rs.randint(-2**31, 2**31, size=ks_words, dtype=np.int64).astype(np.int32)).to(bcast_dev)
+        bk_h, ks_h = tfhe_amd.keygen(p, s_lv0, s_ring, alpha_lv0, alpha_lv1, seed=2026, device=dev_index)
+        bk = torch.from_numpy(bk_h.reshape(-1).view(np.int32)).to(bcast_dev)
+        ks = torch.from_numpy(ks_h.reshape(-1).view(np.int32)).to(bcast_dev)
+        del bk_h, ks_h
     else:
         bk = torch.empty(bk_words, dtype=torch.int32, device=bcast_dev)
         ks = torch.empty(ks_words, dtype=torch.int32, device=bcast_dev)
     t_bcast = 0.0
     if world > 1:
+        # the first collective creates the communicator: keep it out of the broadcast time
+        warm = torch.zeros(1, dtype=torch.int32, device=bcast_dev)
+        dist.broadcast(warm, src=0)
         torch.cuda.synchronize()
-        t0 = time.time()
+        dist.barrier()
+        t0 = time.perf_counter()
         dist.broadcast(bk, src=0)   # RCCL over xGMI, once per key
         dist.broadcast(ks, src=0)
         torch.cuda.synchronize()
-        t_bcast = time.time() - t0
+        t_bcast = time.perf_counter() - t0
     bk, ks = bk.to(dev), ks.to(dev)
+    torch.cuda.synchronize()
     ctx = tfhe_amd.Context(p, bk, ks, device=dev_index, keys_on_device=True)
     if ctx.kernel_family() != "ntt512":
         raise SystemExit(f"bench: expected the NTT kernels of the default parameter set, got {ctx.kernel_family()}")
@@ -139,11 +153,25 @@ def main():
         ctx_ref = tfhe_amd.Context(p, bk, ks, device=dev_index, keys_on_device=True, reference_fft=True)
     del bk, ks
 
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1000 + rank)
-    a = torch.randint(-2**31, 2**31 - 1, (G, n1), dtype=torch.int32, device=dev, generator=gen)
-    b = torch.randint(-2**31, 2**31 - 1, (G, n1), dtype=torch.int32, device=dev, generator=gen)
+    # this rank's gates: fresh encryptions of random bits, b = <a, s> + m + e (reference src/tlwe.hpp:55-61)
+    rs_in = np.random.RandomState(1000 + rank)
+
+    def encrypt(bits):
+        ct = rs_in.randint(0, 2**32, size=(bits.size, n1), dtype=np.uint64).astype(np.uint32)
+        noise = np.floor(np.mod(rs_in.normal(0.0, alpha_lv0, bits.size), 1.0) * 2.0**32).astype(np.uint64).astype(np.uint32)
+        msg = np.where(bits == 1, np.uint32(1 << 29), np.uint32((1 << 32) - (1 << 29))).astype(np.uint32)
+        ct[:, 0] = (ct[:, 1:].astype(np.uint64) @ s_lv0.astype(np.uint64)).astype(np.uint32) + msg + noise
+        return ct
+
+    def decrypt(ct):   # top bit of the phase clear = true (reference src/tlwe.hpp:67-75, src/types.hpp:46)
+        phase = ct[:, 0] - (ct[:, 1:].astype(np.uint64) @ s_lv0.astype(np.uint64)).astype(np.uint32)
+        return (phase < np.uint32(1 << 31)).astype(np.int64)
+
+    bits_a, bits_b = rs_in.randint(0, 2, G), rs_in.randint(0, 2, G)
+    a = torch.from_numpy(encrypt(bits_a).view(np.int32)).to(dev)
+    b = torch.from_numpy(encrypt(bits_b).view(np.int32)).to(dev)
     out = torch.empty_like(a)
+    torch.cuda.synchronize()
 
     def barrier():
         ctx.synchronize()
@@ -169,6 +197,12 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    # every rank decrypts what its last timed step produced and checks it against the plaintext NAND
+    wrong_local = int(np.count_nonzero(decrypt(out.cpu().numpy().view(np.uint32)) != 1 - (bits_a & bits_b)))
+    wrong = torch.tensor([wrong_local], dtype=torch.int64, device=bcast_dev)
+    if world > 1:
+        dist.all_reduce(wrong, op=dist.ReduceOp.SUM)
+    wrong = int(wrong.item())
 
     if rank == 0:
         total_gates = G * world * args.steps
@@ -180,7 +214,7 @@ def main():
             "metric": "bootstrapped NAND gates/sec (whole node)",
             "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 torus; NTT over a 51-bit prime evaluated in f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32 torus; NTT over a 51-bit prime evaluated in f64", "data": "synthetic (keys generated on the GPU from random secrets, fresh encryptions of random bits)",
             "config": {"workload": f"{G} independent NAND gates per GPU per step, default params (n=636, N=512, K=2, "
                                    f"L=2, T=5): one GPU's shard of the 65,536-gate configuration",
                        "gates_per_gpu": G, "params": "default", "parallelism": f"gate-sharded x{world}, keys replicated"},
@@ -192,10 +226,12 @@ def main():
                          "io_GBps": IO_BYTES_PER_GATE * G / (elapsed / args.steps) / 1e9,
                          "note": "peak = 39.3e12 FP64 lane-instructions/s / 7.69 FP64 instructions per modmul-equivalent"},
             "key_broadcast_s": t_bcast,
+            "verified": {"gates_decrypted": G * world, "wrong": wrong,
+                         "how": "every rank decrypts the outputs of its last timed step and compares with NAND of the plaintext bits"},
         }
         # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE),
         # which cannot run inside this process: the committed summary of the latest passes is quoted
-        pmc = sorted((ROOT / "profiles").glob("*_pmc_summary.json"))
+        pmc = [ROOT / "profiles" / PMC_SUMMARY] if (ROOT / "profiles" / PMC_SUMMARY).exists() else []
         if pmc:
             k = json.loads(pmc[-1].read_text())["kernels"].get("blind_rotate_512_kernel", {})
             if "hbm_bytes_per_launch" in k:
@@ -257,6 +293,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(p, args.cpu_sample_gates, threads)
         print(json.dumps(line), flush=True)
     ctx.close()
+    if wrong:
+        raise SystemExit(f"bench: {wrong} gates decrypted to the wrong bit")
     if world > 1:
         dist.destroy_process_group()
 

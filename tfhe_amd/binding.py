@@ -324,12 +324,19 @@ class Context:
         return out
 
     # ---- GPU tensors (torch), asynchronous on `stream` (a torch stream or None) -------------
-    @staticmethod
-    def _stream_ptr(stream):
-        """None -> the context's own stream; a torch stream -> that stream (the default stream's
-        handle is 0, which the C ABI spells TFHE_AMD_DEFAULT_STREAM = (void*)-1)."""
-        if stream is None:
+    OWN_STREAM = "own"
+
+    def _stream_ptr(self, stream):
+        """None -> torch's current stream on the context's GPU, so that the call is ordered behind
+        whatever produced its tensors; Context.OWN_STREAM -> the context's own stream (the caller
+        orders it against the producers); a torch stream -> that stream.  The default stream's
+        handle is 0, which the C ABI spells TFHE_AMD_DEFAULT_STREAM = (void*)-1."""
+        if stream == self.OWN_STREAM:
             return None
+        if stream is None:
+            import torch
+
+            stream = torch.cuda.current_stream(self.device)
         handle = stream.cuda_stream
         return C.c_void_p(handle if handle else C.c_void_p(-1).value)
 
@@ -422,7 +429,14 @@ class Context:
         return library().tfhe_amd_ctx_kernel_family(self._h).decode()
 
     def synchronize(self):
+        """Waits for the context's own stream and, when torch is loaded, for torch's current stream
+        on the context's GPU (where the *_device calls go by default)."""
         _check(library().tfhe_amd_ctx_synchronize(self._h))
+        import sys
+
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.current_stream(self.device).synchronize()
 
     def enable_timing(self, enable=True):
         _check(library().tfhe_amd_ctx_enable_timing(self._h, 1 if enable else 0))
