@@ -121,7 +121,7 @@ struct tfhe_amd_ctx {
     bool replica = false;          // products through a replay of the reference's FFT (verification)
     bool replica_generic = false;  // ... with the one-workgroup-per-gate kernel even at the default set
     d2* d_spec = nullptr;          // replica: key spectra
-    int parts = 1, shift = 0;      // key split of the wg path
+    int tiles = 0, shift = 0, pack_shift = 0;  // key split of the wg path (wg_kernels.hip)
     NttUniform u{};
     d2* d_tw = nullptr;
     d2* d_bk_ntt = nullptr;        // fast path
@@ -435,7 +435,7 @@ int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, u
                                         extract, ctx->form, s));
     else if (ctx->wg)
         HIP_TRY(launch_blind_rotate_wg(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, n_gates, p.n, p.N, p.K, p.L,
-                                       ctx->parts, ctx->shift, extract, s));
+                                       ctx->shift, ctx->pack_shift, extract, s));
     else
         HIP_TRY(launch_blind_rotate_generic(ctx->d_bk_raw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit, extract,
                                             s));
@@ -649,7 +649,8 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     ctx->replica_generic = ctx->replica && (flags & TFHE_AMD_CTX_GENERIC_KERNELS);
     const bool special = !ctx->replica && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
     ctx->fast = special && fast_supported(p);
-    ctx->wg = special && !ctx->fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit);
+    ctx->wg = special && !ctx->fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit) &&
+              wg_split(p->N, p->K, p->L, p->bg_bit, &ctx->tiles, &ctx->shift, &ctx->pack_shift);
     ctx->form = (flags & TFHE_AMD_CTX_LATENCY_FORM) ? 1 : (flags & TFHE_AMD_CTX_THROUGHPUT_FORM) ? 2 : 0;
     auto bail = [&](hipError_t e, const char* what) {
         tfhe_amd_ctx_destroy(ctx);
@@ -700,17 +701,17 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
             const std::vector<double> blk = p->N == 2048   ? build_tw_table_wg<11>(tw)
                                             : p->N == 1024 ? build_tw_table_wg<10>(tw)
                                                            : build_tw_table_wg<9>(tw);
-            wg_split(p->N, p->K, p->L, p->bg_bit, &ctx->parts, &ctx->shift);
             CTX_TRY(hipMalloc(&ctx->d_tw, blk.size() * sizeof(double)));
             CTX_TRY(hipMemcpy(ctx->d_tw, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));
-            CTX_TRY(hipMalloc(&ctx->d_bk_ntt, bk_words * ctx->parts * sizeof(double)));
+            // [n][R][tiles] polynomials of N doubles
+            CTX_TRY(hipMalloc(&ctx->d_bk_ntt, bk_words / (p->K + 1) * ctx->tiles * sizeof(double)));
             if (!on_device) {
                 CTX_TRY(up_bk.alloc(bk_words * sizeof(uint32_t)));
                 CTX_TRY(hipMemcpyAsync(up_bk.p, bk, bk_words * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
                 src = up_bk.as<uint32_t>();
             }
-            CTX_TRY(launch_bk_transform_wg(ctx->u, ctx->d_tw, src, ctx->d_bk_ntt, bk_words / p->N, p->N, ctx->parts,
-                                           ctx->shift, ctx->stream));
+            CTX_TRY(launch_bk_transform_wg(ctx->u, ctx->d_tw, src, ctx->d_bk_ntt, bk_words / p->N / (p->K + 1), p->N, p->K,
+                                           ctx->shift, ctx->pack_shift, ctx->stream));
         } else {
             CTX_TRY(hipMalloc(&ctx->d_bk_raw, bk_words * sizeof(uint32_t)));
             CTX_TRY(hipMemcpyAsync(ctx->d_bk_raw, bk, bk_words * sizeof(uint32_t),

@@ -60,11 +60,11 @@ hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks_packed, uin
 // workgroup-cooperative NTT path for N >= 1024 (wg_kernels.hip)
 bool wg_has_kernel(int N, int K, int L, int bg);
 int wg_table_pairs(int N);
-void wg_split(int N, int K, int L, int bg, int* parts, int* shift);
-hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_polys,
-                                  int N, int parts, int shift, hipStream_t stream);
+bool wg_split(int N, int K, int L, int bg, int* tiles, int* shift, int* pack_shift);
+hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_rows,
+                                  int N, int K, int shift, int pack_shift, hipStream_t stream);
 hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2* bk_ntt, const uint32_t* c,
                                   const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L,
-                                  int parts, int shift, int extract, hipStream_t stream);
+                                  int shift, int pack_shift, int extract, hipStream_t stream);
 
 }  // namespace tfhe_amd

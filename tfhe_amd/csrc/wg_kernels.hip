@@ -5,10 +5,15 @@
 //
 // The field's prime (p/2 = 2^49.6) is smaller than the largest negacyclic accumulation of these
 // sets ((K+1) L N 2^7 2^31 = 2^51.6 for N = 2048, K = 1, L = 3), so the bootstrapping key is split
-// before it is transformed: bk = hi * 2^shift + lo with signed halves, each half is transformed
-// and accumulated separately (each sum is then below 2^36), and the two exact integer results
-// are recombined modulo 2^32 after the inverse transforms.  Same reference semantics as
-// kernels.hip (reference src/trgsw.hpp:131-182).
+// before it is transformed: bk = hi * 2^shift + lo with a signed remainder lo of `shift` bits and a
+// few-bit quotient hi.  Every column's lo part is accumulated on its own (sums below p/2 by the choice
+// of shift).  The hi parts are tiny, so those of two columns share one accumulator, packed as
+// hi_even + 2^pack_shift * hi_odd: their two exact sums are separated again after the inverse
+// transform, and each column's result is lo_sum + (hi_sum << shift) modulo 2^32.  A step therefore
+// costs (K+1) L forward transforms, (K+1) + ceil((K+1)/2) inverse transforms and as many pointwise
+// products per digit polynomial (3 + 3 for K = 1, against the 2 + 2 of a modulus wide enough for the
+// whole sum and the 4 + 4 of two full halves).  Same reference semantics as kernels.hip (reference
+// src/trgsw.hpp:131-182).
 #include "kernels.hpp"
 #include "ntt_wg.hpp"
 
@@ -16,33 +21,38 @@ namespace tfhe_amd {
 
 // signed split v = hi * 2^shift + lo, lo in [-2^(shift-1), 2^(shift-1))
 __device__ __forceinline__ int32_t split_lo(int32_t v, int shift) { return (int32_t)((uint32_t)v << (32 - shift)) >> (32 - shift); }
+__device__ __forceinline__ int32_t split_hi(int32_t v, int shift) { return (int32_t)(((int64_t)v - split_lo(v, shift)) >> shift); }
 
-// One workgroup per (polynomial, part).  Stored value: NTT(part of centred bk) / N, centred, in
-// the order [pair kk in 0..3][thread t][2] of the transform's output layout (position 8t + k).
+// Transformed key layout: [n][R][TILES] polynomials with TILES = K1 + ceil(K1 / 2): tile c < K1 is the
+// lo part of column c, tile K1 + j the packed hi parts of columns 2j and 2j + 1.  One workgroup per
+// (row, tile).  Stored value: NTT(tile) / N, centred, in the order [pair kk in 0..3][thread t][2] of
+// the transform's output layout (position 8t + k).
 template <int LOGN>
 __global__ void __launch_bounds__(WgNtt<LOGN>::T)
 bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const uint32_t* __restrict__ bk,
-                       d2* __restrict__ bk_ntt, int parts, int shift) {
+                       d2* __restrict__ bk_ntt, int K1, int shift, int pack_shift) {
     using W = WgNtt<LOGN>;
     __shared__ double s_tr[W::BUF_DOUBLES];
     const int t = threadIdx.x;
-    const size_t poly = blockIdx.x / parts;
-    const int part = blockIdx.x % parts;
-    const uint32_t* src = bk + poly * W::N;
+    const int tiles = K1 + (K1 + 1) / 2;
+    const size_t row = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles;
+    const uint32_t* src = bk + row * K1 * W::N;
     double x[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int32_t v = (int32_t)src[k * W::T + t];
-        int32_t piece = v;
-        if (parts == 2) {
-            const int32_t lo = split_lo(v, shift);
-            piece = part == 0 ? lo : (int32_t)(((int64_t)v - lo) >> shift);
+        const int j = k * W::T + t;
+        if (tile < K1) {
+            x[k] = (double)split_lo((int32_t)src[(size_t)tile * W::N + j], shift);
+        } else {
+            const int c0 = 2 * (tile - K1), c1 = c0 + 1;
+            double v = (double)split_hi((int32_t)src[(size_t)c0 * W::N + j], shift);
+            if (c1 < K1) v += (double)split_hi((int32_t)src[(size_t)c1 * W::N + j], shift) * (double)(1 << pack_shift);
+            x[k] = v;  // |v| <= 2^(32 - shift) (1 + 2^pack_shift) < 2^31
         }
-        x[k] = (double)piece;
     }
     int parity = 0;
     W::template forward<false>(x, u, table, s_tr, parity, t);
-    // transformed key: [.. r][col][part], i.e. raw polynomial index * parts + part = blockIdx.x
     d2* dst = bk_ntt + ((size_t)blockIdx.x) * (W::N / 2);
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
@@ -53,18 +63,18 @@ bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const u
     }
 }
 
-// Transformed key layout: [n][R][K1][parts] polynomials (part innermost), each [4][T][2] doubles.
 // Two workgroups per CU (<= 256 registers per lane, 71 KB of LDS each): while one waits at a
 // transpose barrier the other one computes.  Measured alternatives: one workgroup per CU with
 // the L digit transforms of a polynomial interleaved in each wave (more parallelism per wave,
 // fewer barriers) is 20 % slower, three workgroups per CU spill and are 35 % slower.
-template <int LOGN, int K, int L, int PARTS>
+template <int LOGN, int K, int L>
 __global__ void __launch_bounds__(WgNtt<LOGN>::T, 2)
 blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d2* __restrict__ bk_ntt,
                        const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv, uint32_t* __restrict__ out,
-                       int n, int shift, int extract) {
+                       int n, int shift, int pack_shift, int extract) {
     using W = WgNtt<LOGN>;
     constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L, BG = 8;
+    constexpr int PACKS = (K1 + 1) / 2, TILES = K1 + PACKS;
     __shared__ double s_tr[W::BUF_DOUBLES];
     __shared__ uint32_t s_acc[K1][N];
     const int t = threadIdx.x;
@@ -94,20 +104,19 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
         offset += 1u << (32 - BG * (l + 1) + BG - 1);
         flip |= 1u << (32 - BG * (l + 1) + BG - 1);
     }
+    const double unpack = 1.0 / (double)(1u << pack_shift), pack = (double)(1u << pack_shift);
 
     int parity = 0;
     for (int i = 0; i < n; i++) {
         const int abar = (int)((cg[1 + i] + (1u << (SH - 1))) >> SH);
 
-        double acc_ntt[K1][PARTS][8];
+        double acc_ntt[TILES][8];
 #pragma unroll
-        for (int col = 0; col < K1; col++)
+        for (int tile = 0; tile < TILES; tile++)
 #pragma unroll
-            for (int part = 0; part < PARTS; part++)
-#pragma unroll
-                for (int k = 0; k < 8; k++) acc_ntt[col][part][k] = 0.0;
+            for (int k = 0; k < 8; k++) acc_ntt[tile][k] = 0.0;
 
-        const d2* bk_row = bk_ntt + (size_t)i * (R * K1 * PARTS) * (N / 2);
+        const d2* bk_row = bk_ntt + (size_t)i * (R * TILES) * (N / 2);
 #pragma unroll 1
         for (int q = 0; q < K1; q++) {
             uint32_t tw_[8];
@@ -121,11 +130,9 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
 #pragma unroll 1
             for (int level = 0; level < L; level++) {  // rolled: keeps one transform's worth of code and registers live
                 const int r = q * L + level;
-                const d2* bk_poly = bk_row + (size_t)r * (K1 * PARTS) * (N / 2);
-                // Key row: column 0 is requested before the transform, every further column while
-                // the previous one is being multiplied, so that at most two columns are in flight.
-                // Key row: K1 * PARTS tiles of 4 pairs per thread; tile 0 is requested before the
-                // transform, every further tile while the previous one is being multiplied.
+                const d2* bk_poly = bk_row + (size_t)r * TILES * (N / 2);
+                // Key row: TILES tiles of 4 pairs per thread; tile 0 is requested before the transform,
+                // every further tile while the previous one is being multiplied.
                 d2 y[4], ynext[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++) y[kk] = bk_poly[kk * T + t];
@@ -134,18 +141,23 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                 for (int k = 0; k < 8; k++) x[k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
                 W::template forward<true>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
 #pragma unroll
-                for (int tile = 0; tile < K1 * PARTS; tile++) {
-                    const int col = tile / PARTS, part = tile % PARTS;
-                    if (tile + 1 < K1 * PARTS) {
+                for (int tile = 0; tile < TILES; tile++) {
+                    if (tile + 1 < TILES) {
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) ynext[kk] = bk_poly[(size_t)(tile + 1) * (N / 2) + kk * T + t];
                     }
+                    // the eight products of a tile phase by phase (ntt512.hpp): dependent FP64
+                    // instructions end up eight apart instead of back to back
+                    double yy[8], prod[8];
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
-                        acc_ntt[col][part][2 * kk] += mulmod_var(x[2 * kk], y[kk].x, p, pinv);
-                        acc_ntt[col][part][2 * kk + 1] += mulmod_var(x[2 * kk + 1], y[kk].y, p, pinv);
+                        yy[2 * kk] = y[kk].x;
+                        yy[2 * kk + 1] = y[kk].y;
                     }
-                    if (tile + 1 < K1 * PARTS) {
+                    mulmod_var_n<8>(prod, x, yy, p, pinv);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc_ntt[tile][k] += prod[k];
+                    if (tile + 1 < TILES) {
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) y[kk] = ynext[kk];
                     }
@@ -153,28 +165,30 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                 // products are <= 1.41 p each: reduce after every third (running sum < 4.74 p)
                 if (r % 3 == 2 && r != R - 1) {
 #pragma unroll
-                    for (int col = 0; col < K1; col++)
-#pragma unroll
-                        for (int part = 0; part < PARTS; part++)
-#pragma unroll
-                            for (int k = 0; k < 8; k++)
-                                acc_ntt[col][part][k] = reduce(acc_ntt[col][part][k], p, pinv);
+                    for (int tile = 0; tile < TILES; tile++) reduce_n<8>(acc_ntt[tile], p, pinv);
                 }
+            }
+        }
+        // hi sums first: every packed accumulator yields the small exact sums of two columns
+        uint32_t hi_sum[K1][8];
+#pragma unroll
+        for (int j = 0; j < PACKS; j++) {
+            W::inverse(acc_ntt[K1 + j], u, table, s_tr, parity, t);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double v = reduce(acc_ntt[K1 + j][k], p, pinv);  // exact: h_even + 2^pack_shift h_odd
+                const double h1 = __builtin_rint(v * unpack);
+                const double h0 = __builtin_fma(-h1, pack, v);
+                hi_sum[2 * j][k] = (uint32_t)(int32_t)h0;
+                if (2 * j + 1 < K1) hi_sum[2 * j + 1][k] = (uint32_t)(int32_t)h1;
             }
         }
 #pragma unroll
         for (int col = 0; col < K1; col++) {
-            uint32_t delta[8];
+            W::inverse(acc_ntt[col], u, table, s_tr, parity, t);
 #pragma unroll
-            for (int k = 0; k < 8; k++) delta[k] = 0u;
-#pragma unroll
-            for (int part = 0; part < PARTS; part++) {
-                W::inverse(acc_ntt[col][part], u, table, s_tr, parity, t);
-#pragma unroll
-                for (int k = 0; k < 8; k++) delta[k] += to_torus(acc_ntt[col][part][k], p, pinv) << (part * shift);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) s_acc[col][k * T + t] += delta[k];
+            for (int k = 0; k < 8; k++)
+                s_acc[col][k * T + t] += to_torus(acc_ntt[col][k], p, pinv) + (hi_sum[col][k] << shift);
         }
         __syncthreads();
     }
@@ -210,20 +224,36 @@ int wg_table_pairs(int N) {
     return N == 2048 ? WgNtt<11>::TABLE_PAIRS : N == 1024 ? WgNtt<10>::TABLE_PAIRS : N == 512 ? WgNtt<9>::TABLE_PAIRS : 0;
 }
 
-// number of key parts and the split position for a parameter set: one part if the largest
-// accumulation (K+1) L N 2^(bg-1) 2^31 stays below p/2 with margin, else two halves of 16 bits
-void wg_split(int N, int K, int L, int bg, int* parts, int* shift) {
-    const double bound = (double)(K + 1) * L * N * (double)(1u << (bg - 1)) * 2147483648.0;
-    if (bound < 0.49 * 1711528530149377.0) { *parts = 1; *shift = 0; }
-    else { *parts = 2; *shift = 16; }
+// Split of the key for a parameter set (see the top of this file): `shift` = bits of the signed
+// remainder lo, chosen so that a column's lo sum (K+1) L N 2^(bg-1) 2^(shift-1) stays below p/4;
+// `pack_shift` = position of the odd column's hi sum inside a packed accumulator, the smallest with
+// 2^(pack_shift-1) above one hi sum H = (K+1) L N 2^(bg-1) 2^(32-shift-1) (so that rounding separates
+// the two) -- the packed sum H (1 + 2^pack_shift) must stay below p/2 as well.  Returns false if no
+// such split exists.  `tiles` = polynomials per key row after the split.
+bool wg_split(int N, int K, int L, int bg, int* tiles, int* shift, int* pack_shift) {
+    const double pp = 1711528530149377.0;
+    const double terms = (double)(K + 1) * L * N * (double)(1u << (bg - 1));
+    for (int s = 30; s >= 16; s--) {
+        if (terms * (double)(1u << (s - 1)) >= 0.25 * pp) continue;
+        const double H = terms * (double)(1u << (32 - s - 1));
+        int ps = 1;
+        while ((double)(1u << (ps - 1)) <= H) ps++;
+        if (ps > 30 || H * (1.0 + (double)(1u << ps)) >= 0.49 * pp) return false;
+        *tiles = (K + 1) + (K + 2) / 2;
+        *shift = s;
+        *pack_shift = ps;
+        return true;
+    }
+    return false;
 }
 
-hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_polys,
-                                  int N, int parts, int shift, hipStream_t stream) {
-    if (n_polys == 0) return hipSuccess;
-#define WG_KEY(LOGN)                                                                                                 \
-    bk_transform_wg_kernel<LOGN><<<(unsigned)(n_polys * parts), WgNtt<LOGN>::T, 0, stream>>>(u, table, bk, bk_ntt, parts, \
-                                                                                             shift)
+hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_rows,
+                                  int N, int K, int shift, int pack_shift, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    const int tiles = (K + 1) + (K + 2) / 2;
+#define WG_KEY(LOGN)                                                                                               \
+    bk_transform_wg_kernel<LOGN><<<(unsigned)(n_rows * tiles), WgNtt<LOGN>::T, 0, stream>>>(u, table, bk, bk_ntt, K + 1, \
+                                                                                           shift, pack_shift)
     if (N == 2048) WG_KEY(11);
     else if (N == 1024) WG_KEY(10);
     else if (N == 512) WG_KEY(9);
@@ -234,20 +264,21 @@ hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const ui
 
 hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2* bk_ntt, const uint32_t* c,
                                   const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L,
-                                  int parts, int shift, int extract, hipStream_t stream) {
+                                  int shift, int pack_shift, int extract, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
     if (!wg_has_kernel(N, K, L, 8)) return hipErrorInvalidValue;
-    int want_parts = 0, want_shift = 0;
-    wg_split(N, K, L, 8, &want_parts, &want_shift);
-    if (parts != want_parts) return hipErrorInvalidValue;
-#define WG_GO(LOGN, KK, LL, PP)                                                                                       \
-    blind_rotate_wg_kernel<LOGN, KK, LL, PP><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, \
-                                                                                               out, n, shift, extract)
-    if (N == 2048) { if (L == 3) WG_GO(11, 1, 3, 2); else WG_GO(11, 1, 2, 2); }
-    else if (N == 1024 && K == 1) { if (L == 3) WG_GO(10, 1, 3, 2); else WG_GO(10, 1, 2, 2); }
-    else if (N == 1024) { if (L == 3) WG_GO(10, 2, 3, 2); else WG_GO(10, 2, 2, 2); }
-    else if (K == 1) WG_GO(9, 1, 3, 2);
-    else WG_GO(9, 2, 3, 2);
+    // the key must have been split the way this parameter set requires (the kernels assume it)
+    int want_tiles = 0, want_shift = 0, want_pack = 0;
+    if (!wg_split(N, K, L, 8, &want_tiles, &want_shift, &want_pack) || shift != want_shift || pack_shift != want_pack)
+        return hipErrorInvalidValue;
+#define WG_GO(LOGN, KK, LL)                                                                                       \
+    blind_rotate_wg_kernel<LOGN, KK, LL><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, out, n, \
+                                                                                           shift, pack_shift, extract)
+    if (N == 2048) { if (L == 3) WG_GO(11, 1, 3); else WG_GO(11, 1, 2); }
+    else if (N == 1024 && K == 1) { if (L == 3) WG_GO(10, 1, 3); else WG_GO(10, 1, 2); }
+    else if (N == 1024) { if (L == 3) WG_GO(10, 2, 3); else WG_GO(10, 2, 2); }
+    else if (K == 1) WG_GO(9, 1, 3);
+    else WG_GO(9, 2, 3);
 #undef WG_GO
     return hipGetLastError();
 }
