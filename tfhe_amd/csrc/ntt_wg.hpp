@@ -59,6 +59,19 @@ struct WgNtt {
         asm volatile("" : "+v"(v));
         return v;
     }
+#ifndef TFHE_AMD_WG_EXPERIMENT
+#define TFHE_AMD_WG_EXPERIMENT 0
+#endif
+    // timing experiments (wrong results): 1 = every thread reads twiddle row 0 of its group,
+    // 2 = no twiddle loads (thread-uniform values), 3 = no block barrier in the transposes
+    __device__ static __forceinline__ void load_row(Tw7& tw, const d2* rows, int row, const NttUniform& u) {
+        if (TFHE_AMD_WG_EXPERIMENT == 2) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) { tw.w[i] = u.fw[1 + i]; tw.wp[i] = u.fwp[1 + i]; }
+            return;
+        }
+        load_tw7(tw, rows + 7 * (TFHE_AMD_WG_EXPERIMENT == 1 ? opaque(0) : row));
+    }
 
     // registers in layout `from` -> registers in layout `to`.  bufs: BUF_DOUBLES doubles; `parity`
     // selects the block buffer and is advanced once per block-level transpose.
@@ -77,7 +90,7 @@ struct WgNtt {
         parity++;
 #pragma unroll
         for (int k = 0; k < 8; k++) buf[pad_pos(position(from, t, k))] = x[k];
-        __syncthreads();
+        if (TFHE_AMD_WG_EXPERIMENT != 3) __syncthreads();
 #pragma unroll
         for (int k = 0; k < 8; k++) x[k] = buf[pad_pos(position(to, t, k))];
     }
@@ -123,86 +136,114 @@ struct WgNtt {
         }
     }
 
-    // Forward.  In: group-0 layout (position k*T + t), |x| <= 2^31 (SMALL: |x| <= 2^7).
+    // M forward transforms group by group, so that every group's twiddle row is loaded once for
+    // all of them.  In: group-0 layout (position k*T + t), |x| <= 2^31 (SMALL: |x| <= 2^7).
     // Out: last group's layout (position 8t + k, bit-reversed spectrum order), |x| <= 3.2 p.
     // Additive inputs are reduced at the first stage of groups >= 2 (SMALL) or >= 1; the bound
     // then stays below 4.2 p at every stage for LOGN <= 12.
-    template <bool SMALL>
-    __device__ static __forceinline__ void forward(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
-                                                   double* bufs, int& parity, int t) {
+    template <bool SMALL, int M>
+    __device__ static __forceinline__ void forward_many(double (&xs)[M][8], const NttUniform& u,
+                                                        const d2* __restrict__ table, double* bufs, int& parity, int t) {
         const double p = u.p, pinv = u.pinv;
-        if (SMALL) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const double a = x[k], b = x[k + 4];
-                x[k] = __builtin_fma(b, u.zI, a);
-                x[k + 4] = __builtin_fma(-b, u.zI, a);
+        for (int m = 0; m < M; m++) {
+            double (&x)[8] = xs[m];
+            if (SMALL) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double a = x[k], b = x[k + 4];
+                    x[k] = __builtin_fma(b, u.zI, a);
+                    x[k + 4] = __builtin_fma(-b, u.zI, a);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const double a = x[k], b = x[k + 2];
+                    x[k] = __builtin_fma(b, u.z, a);
+                    x[k + 2] = __builtin_fma(-b, u.z, a);
+                }
+#pragma unroll
+                for (int k = 4; k < 6; k++) bf_ct(x[k], x[k + 2], u.fw[3], u.fwp[3], p);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) bf_ct(x[k], x[k + 4], u.fw[1], u.fwp[1], p);
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int k = 0; k < 2; k++) bf_ct(x[4 * h + k], x[4 * h + k + 2], u.fw[2 + h], u.fwp[2 + h], p);
             }
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const double a = x[k], b = x[k + 2];
-                x[k] = __builtin_fma(b, u.z, a);
-                x[k + 2] = __builtin_fma(-b, u.z, a);
-            }
-#pragma unroll
-            for (int k = 4; k < 6; k++) bf_ct(x[k], x[k + 2], u.fw[3], u.fwp[3], p);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) bf_ct(x[k], x[k + 4], u.fw[1], u.fwp[1], p);
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int k = 0; k < 2; k++) bf_ct(x[4 * h + k], x[4 * h + k + 2], u.fw[2 + h], u.fwp[2 + h], p);
+            for (int g = 0; g < 4; g++) bf_ct(x[2 * g], x[2 * g + 1], u.fw[4 + g], u.fwp[4 + g], p);
         }
-#pragma unroll
-        for (int g = 0; g < 4; g++) bf_ct(x[2 * g], x[2 * g + 1], u.fw[4 + g], u.fwp[4 + g], p);
-
 #pragma unroll
         for (int g = 1; g < GROUPS; g++) {
             // keeps the compiler from hoisting every group's twiddle loads (28 registers each) to
             // the top of the transform
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
-            load_tw7(tw, table + 7 * (row_offset(g) + opaque(t >> base(g))));
-            transpose(x, bufs, parity, g - 1, g, t);
-            constexpr bool kAlways = !SMALL;
-            if (g == GROUPS - 1) {
-                ct_group<LAST, true>(x, tw, p, pinv);
-            } else if (g >= 2 || kAlways) {
-                ct_group<3, true>(x, tw, p, pinv);
-            } else {
-                ct_group<3, false>(x, tw, p, pinv);
+            load_row(tw, table + 7 * row_offset(g), opaque(t >> base(g)), u);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                transpose(xs[m], bufs, parity, g - 1, g, t);
+                constexpr bool kAlways = !SMALL;
+                if (g == GROUPS - 1) {
+                    ct_group<LAST, true>(xs[m], tw, p, pinv);
+                } else if (g >= 2 || kAlways) {
+                    ct_group<3, true>(xs[m], tw, p, pinv);
+                } else {
+                    ct_group<3, false>(xs[m], tw, p, pinv);
+                }
             }
         }
     }
 
-    // Inverse without the 1/N factor.  In: last group's layout, |x| < 2^53.  Out: group-0 layout,
-    // |x| <= 4 p.  Every group starts from |x| <= p/2.
-    __device__ static __forceinline__ void inverse(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
+    template <bool SMALL>
+    __device__ static __forceinline__ void forward(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
                                                    double* bufs, int& parity, int t) {
+        double (&one)[1][8] = reinterpret_cast<double (&)[1][8]>(x);
+        forward_many<SMALL, 1>(one, u, table, bufs, parity, t);
+    }
+
+    // M inverse transforms without the 1/N factor, group by group, so that every group's twiddle
+    // row is loaded once for all of them.  In: last group's layout, |x| < 2^53.  Out: group-0
+    // layout, |x| <= 4 p.  Every group starts from |x| <= p/2.
+    template <int M>
+    __device__ static __forceinline__ void inverse_many(double (&x)[M][8], const NttUniform& u,
+                                                        const d2* __restrict__ table, double* bufs, int& parity, int t) {
         const double p = u.p, pinv = u.pinv;
         const d2* inv_table = table + 7 * TABLE_ROWS;
 #pragma unroll
         for (int g = GROUPS - 1; g >= 1; g--) {
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
-            load_tw7(tw, inv_table + 7 * (row_offset(g) + opaque(t >> base(g))));
+            load_row(tw, inv_table + 7 * row_offset(g), opaque(t >> base(g)), u);
 #pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
-            if (g == GROUPS - 1) gs_group<LAST>(x, tw, p);
-            else                 gs_group<3>(x, tw, p);
-            transpose(x, bufs, parity, g, g - 1, t);
+            for (int m = 0; m < M; m++) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[m][k] = reduce(x[m][k], p, pinv);
+                if (g == GROUPS - 1) gs_group<LAST>(x[m], tw, p);
+                else                 gs_group<3>(x[m], tw, p);
+                transpose(x[m], bufs, parity, g, g - 1, t);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = reduce(x[k], p, pinv);
+        for (int m = 0; m < M; m++) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], u.iw[4 + g], u.iwp[4 + g], p);
+            for (int k = 0; k < 8; k++) x[m][k] = reduce(x[m][k], p, pinv);
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+            for (int g = 0; g < 4; g++) bf_gs(x[m][2 * g], x[m][2 * g + 1], u.iw[4 + g], u.iwp[4 + g], p);
 #pragma unroll
-            for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], u.iw[2 + h], u.iwp[2 + h], p);
+            for (int h = 0; h < 2; h++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], u.iw[1], u.iwp[1], p);
+                for (int k = 0; k < 2; k++) bf_gs(x[m][4 * h + k], x[m][4 * h + k + 2], u.iw[2 + h], u.iwp[2 + h], p);
+#pragma unroll
+            for (int k = 0; k < 4; k++) bf_gs(x[m][k], x[m][k + 4], u.iw[1], u.iwp[1], p);
+        }
+    }
+
+    __device__ static __forceinline__ void inverse(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
+                                                   double* bufs, int& parity, int t) {
+        double (&one)[1][8] = reinterpret_cast<double (&)[1][8]>(x);
+        inverse_many<1>(one, u, table, bufs, parity, t);
     }
 };
 

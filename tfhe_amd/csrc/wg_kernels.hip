@@ -127,24 +127,28 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                 const uint32_t v = s_acc[q][sidx & (N - 1)];
                 tw_[k] = ((((v ^ neg) - neg) - s_acc[q][k * T + t]) + offset) ^ flip;
             }
-#pragma unroll 1
-            for (int level = 0; level < L; level++) {  // rolled: keeps one transform's worth of code and registers live
-                const int r = q * L + level;
-                const d2* bk_poly = bk_row + (size_t)r * TILES * (N / 2);
-                // Key row: TILES tiles of 4 pairs per thread; tile 0 is requested before the transform,
-                // every further tile while the previous one is being multiplied.
-                d2 y[4], ynext[4];
+            // The L digit polynomials of this accumulator polynomial are transformed group by group
+            // together (one load of every twiddle row serves all of them); then each is multiplied
+            // with its key row: L * TILES tiles of 4 pairs per thread, tile 0 requested before the
+            // transforms, every further tile while the previous one is being multiplied.
+            const d2* bk_poly = bk_row + (size_t)(q * L) * TILES * (N / 2);
+            d2 y[4], ynext[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) y[kk] = bk_poly[kk * T + t];
-                double x[8];
+            for (int kk = 0; kk < 4; kk++) y[kk] = bk_poly[kk * T + t];
+            double x[L][8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
-                W::template forward<true>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
+            for (int level = 0; level < L; level++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[level][k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
+            W::template forward_many<true, L>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
+#pragma unroll
+            for (int level = 0; level < L; level++) {
 #pragma unroll
                 for (int tile = 0; tile < TILES; tile++) {
-                    if (tile + 1 < TILES) {
+                    const int next = level * TILES + tile + 1;
+                    if (next < L * TILES) {
 #pragma unroll
-                        for (int kk = 0; kk < 4; kk++) ynext[kk] = bk_poly[(size_t)(tile + 1) * (N / 2) + kk * T + t];
+                        for (int kk = 0; kk < 4; kk++) ynext[kk] = bk_poly[(size_t)next * (N / 2) + kk * T + t];
                     }
                     // the eight products of a tile phase by phase (ntt512.hpp): dependent FP64
                     // instructions end up eight apart instead of back to back
@@ -154,41 +158,36 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                         yy[2 * kk] = y[kk].x;
                         yy[2 * kk + 1] = y[kk].y;
                     }
-                    mulmod_var_n<8>(prod, x, yy, p, pinv);
+                    mulmod_var_n<8>(prod, x[level], yy, p, pinv);
 #pragma unroll
                     for (int k = 0; k < 8; k++) acc_ntt[tile][k] += prod[k];
-                    if (tile + 1 < TILES) {
+                    if (next < L * TILES) {
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) y[kk] = ynext[kk];
                     }
                 }
-                // products are <= 1.41 p each: reduce after every third (running sum < 4.74 p)
-                if (r % 3 == 2 && r != R - 1) {
+                // products are <= 1.41 p each: reduce after every third digit polynomial (running sum < 4.74 p)
+                if ((q * L + level) % 3 == 2 && q * L + level != R - 1) {
 #pragma unroll
                     for (int tile = 0; tile < TILES; tile++) reduce_n<8>(acc_ntt[tile], p, pinv);
                 }
             }
         }
-        // hi sums first: every packed accumulator yields the small exact sums of two columns
-        uint32_t hi_sum[K1][8];
-#pragma unroll
-        for (int j = 0; j < PACKS; j++) {
-            W::inverse(acc_ntt[K1 + j], u, table, s_tr, parity, t);
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const double v = reduce(acc_ntt[K1 + j][k], p, pinv);  // exact: h_even + 2^pack_shift h_odd
-                const double h1 = __builtin_rint(v * unpack);
-                const double h0 = __builtin_fma(-h1, pack, v);
-                hi_sum[2 * j][k] = (uint32_t)(int32_t)h0;
-                if (2 * j + 1 < K1) hi_sum[2 * j + 1][k] = (uint32_t)(int32_t)h1;
-            }
-        }
+        // all K1 + PACKS inverse transforms group by group: one load of every twiddle row serves them all
+        W::template inverse_many<TILES>(acc_ntt, u, table, s_tr, parity, t);
 #pragma unroll
         for (int col = 0; col < K1; col++) {
-            W::inverse(acc_ntt[col], u, table, s_tr, parity, t);
+            // the packed accumulator holds the small exact hi sums of two columns: h_even + 2^pack_shift h_odd
+            uint32_t hi_sum[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double v = reduce(acc_ntt[K1 + col / 2][k], p, pinv);
+                const double h1 = __builtin_rint(v * unpack);
+                hi_sum[k] = (uint32_t)(int32_t)((col & 1) ? h1 : __builtin_fma(-h1, pack, v));
+            }
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                s_acc[col][k * T + t] += to_torus(acc_ntt[col][k], p, pinv) + (hi_sum[col][k] << shift);
+                s_acc[col][k * T + t] += to_torus(acc_ntt[col][k], p, pinv) + (hi_sum[k] << shift);
         }
         __syncthreads();
     }
