@@ -97,21 +97,25 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx);
  * i.e. TRGSW::make_bk (src/trgsw.hpp:61-82,119-129) and TLWEKeySwitching::make_ks
  * (src/tlwe_key_switching.hpp:26-45).  s_lv0: [n] bytes 0/1 (SecretKey::tlwe_lv0_s); s_ring:
  * [K][N] bytes 0/1 (SecretKey::trlwe_s), both in HOST memory.  alpha_lv0 / alpha_lv1: noise standard
- * deviations of the lv0 TLWE and of the ring (reference src/tlwe.hpp:13, src/trlwe.hpp:12).  Masks
- * and noise come from a counter-based generator keyed by `seed`: the result is a pure function of
- * (secret key, seed).  The reference draws from std::random_device and cannot be reproduced, so
- * generated keys are checked through their decryption, not against reference bytes.
+ * deviations of the lv0 TLWE and of the ring (reference src/tlwe.hpp:13, src/trlwe.hpp:12).  Every
+ * mask and noise word is ChaCha20 output under the 256-bit key `seed` (eight words): the result is
+ * a pure function of (secret key, seed), and the masks are as unpredictable as the seed, which must
+ * therefore be fresh secret randomness (the reference draws every word from std::random_device,
+ * src/random.hpp:10,35-41); a fixed seed is for tests.  Generated keys cannot be compared with
+ * reference bytes (the reference is not reproducible); they are checked word for word against the
+ * CPU oracle's restatement of the same generator and through their decryption.
  *   _keygen:        raw keys to HOST arrays bk / ks (either may be NULL)
  *   _keygen_device: raw keys to DEVICE arrays on GPU `device`, synchronised before returning
  *   _ctx_create_from_secret: keys generated on the GPU and turned into a context without
  *                   ever leaving it */
 int tfhe_amd_keygen(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
-                    double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks);
+                    double alpha_lv1, const uint32_t* seed /*[8]*/, int device, uint32_t* bk, uint32_t* ks);
 int tfhe_amd_keygen_device(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
-                           double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks, void* stream);
+                           double alpha_lv1, const uint32_t* seed /*[8]*/, int device, uint32_t* bk, uint32_t* ks,
+                           void* stream);
 int tfhe_amd_ctx_create_from_secret(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring,
-                                    double alpha_lv0, double alpha_lv1, uint64_t seed, int device, unsigned flags,
-                                    tfhe_amd_ctx** out);
+                                    double alpha_lv0, double alpha_lv1, const uint32_t* seed /*[8]*/, int device,
+                                    unsigned flags, tfhe_amd_ctx** out);
 
 /* HomNAND::nand over a batch (reference src/hom_nand.hpp:74-81): out[g] = NAND(a[g], b[g]).
  * a, b, out: [n_gates][n+1] in HOST memory.  Synchronous. */

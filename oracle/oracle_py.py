@@ -289,6 +289,25 @@ def make_ks(s0, sr, p, r):
     return ks
 
 
+def chacha20_block(seed_words, stream, row, index):
+    out = np.empty(16, dtype=np.uint32)
+    sw = np.ascontiguousarray(seed_words, dtype=np.uint32)
+    lib().tfo_chacha20_block(_p(out), _p(sw), C.c_uint32(stream), C.c_uint64(row), C.c_uint32(index))
+    return out
+
+
+def keygen_chacha(s0, sr, p, alpha_lv0, alpha_lv1, seed_words):
+    """(bk, ks) as the GPU key generator makes them from the same secret key and 256-bit seed."""
+    sw = np.ascontiguousarray(seed_words, dtype=np.uint32)
+    s0 = np.ascontiguousarray(s0, dtype=np.uint8)
+    sr = np.ascontiguousarray(sr, dtype=np.uint8)
+    bk = np.empty(p.bk_shape(), dtype=np.uint32)
+    ks = np.empty(p.ks_shape(), dtype=np.uint32)
+    lib().tfo_keygen_chacha_bk(_p(bk), _p(s0), _p(sr), C.byref(p), C.c_double(alpha_lv1), _p(sw))
+    lib().tfo_keygen_chacha_ks(_p(ks), _p(s0), _p(sr), C.byref(p), C.c_double(alpha_lv0), _p(sw))
+    return bk, ks
+
+
 def encrypt_bits(bits, s0, p, r):
     bits = np.asarray(bits).astype(np.int32).ravel()
     out = np.empty((bits.size, p.n + 1), dtype=np.uint32)

@@ -824,3 +824,127 @@ void tfo_make_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_ring, cons
                 tfo_tlwe_encrypt(row, msg, s_lv0, p->n, p->alpha_lv0, r);
             }
 }
+
+/* ---- restatement of the GPU key generator (tfhe_amd/csrc/keygen_kernels.hip) -------------------------
+ * Same key structure as tfo_make_bk / tfo_make_ks (reference src/trgsw.hpp:61-82,119-129,
+ * src/tlwe_key_switching.hpp:26-45), with every mask and noise word taken from the ChaCha20 block
+ * function (RFC 8439: 20 rounds, feed-forward) under a 256-bit seed, block position (index, stream,
+ * row low, row high) in the counter and nonce words.  Masks are pure generator words, so they are
+ * identical on every machine; the Gaussian noise goes through log, sqrt, sin and cos, whose last-bit
+ * rounding may differ between this libm and the GPU's, so a noise word may differ by one unit where the
+ * scaled normal lies within rounding of an integer. */
+static uint32_t tfo_rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+#define TFO_QR(a, b, c, d)                   \
+    a += b; d ^= a; d = tfo_rotl32(d, 16);   \
+    c += d; b ^= c; b = tfo_rotl32(b, 12);   \
+    a += b; d ^= a; d = tfo_rotl32(d, 8);    \
+    c += d; b ^= c; b = tfo_rotl32(b, 7);
+
+void tfo_chacha20_block(uint32_t out[16], const uint32_t seed[8], uint32_t stream, uint64_t row, uint32_t index) {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    uint32_t x[16];
+    for (int i = 0; i < 8; i++) in[4 + i] = seed[i];
+    in[12] = index; in[13] = stream; in[14] = (uint32_t)row; in[15] = (uint32_t)(row >> 32);
+    memcpy(x, in, sizeof(x));
+    for (int r = 0; r < 10; r++) {
+        TFO_QR(x[0], x[4], x[8], x[12])
+        TFO_QR(x[1], x[5], x[9], x[13])
+        TFO_QR(x[2], x[6], x[10], x[14])
+        TFO_QR(x[3], x[7], x[11], x[15])
+        TFO_QR(x[0], x[5], x[10], x[15])
+        TFO_QR(x[1], x[6], x[11], x[12])
+        TFO_QR(x[2], x[7], x[8], x[13])
+        TFO_QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+
+/* two standard normals from four words: Box-Muller on a 53-bit uniform in (0, 1] and a 52-bit one in [0, 1) */
+static void tfo_normal2(const uint32_t* w, double* z0, double* z1) {
+    const double u1 = ((double)(((uint64_t)w[0] << 21) ^ (w[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = (double)(((uint64_t)w[2] << 20) ^ (w[3] >> 12)) * (1.0 / 4503599627370496.0);
+    const double r = sqrt(-2.0 * log(u1));
+    const double a = 2.0 * u2;          /* angle in units of pi, [0, 2) */
+    /* sin(pi a), cos(pi a) with the argument reduced exactly to [-1/4, 1/4] around a multiple of 1/2 */
+    const double k = floor(a * 2.0 + 0.5);          /* nearest multiple of 1/2 */
+    const double f = (a - k * 0.5) * 3.14159265358979323846;
+    const double sf = sin(f), cf = cos(f);
+    double sv, cv;
+    switch (((int)k) & 3) {
+    case 0: sv = sf; cv = cf; break;
+    case 1: sv = cf; cv = -sf; break;
+    case 2: sv = -sf; cv = -cf; break;
+    default: sv = -cf; cv = sf; break;
+    }
+    *z0 = r * cv;
+    *z1 = r * sv;
+}
+
+enum { TFO_STREAM_BK_MASK = 1, TFO_STREAM_BK_NOISE = 2, TFO_STREAM_KS_MASK = 3, TFO_STREAM_KS_NOISE = 4 };
+
+void tfo_keygen_chacha_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, const tfo_params* p,
+                          double alpha, const uint32_t seed[8]) {
+    const int N = p->N, K = p->K, K1 = K + 1, L = p->L, R = K1 * L;
+    uint32_t w[16];
+    for (int64_t row = 0; row < (int64_t)p->n * R; row++) {
+        const int i = (int)(row / R), r = (int)(row % R), comp = r / L, level = r % L;
+        uint32_t* out = bk + (size_t)row * K1 * N;
+        for (int j = 0; j < N; j += 8) {
+            tfo_chacha20_block(w, seed, TFO_STREAM_BK_NOISE, (uint64_t)row, (uint32_t)(j >> 3));
+            for (int e = 0; e < 4; e++) {
+                double z0, z1;
+                tfo_normal2(w + 4 * e, &z0, &z1);
+                if (j + 2 * e < N) out[j + 2 * e] = tfo_torus_from_double(z0 * alpha);
+                if (j + 2 * e + 1 < N) out[j + 2 * e + 1] = tfo_torus_from_double(z1 * alpha);
+            }
+        }
+        for (int k = 0; k < K; k++) {
+            uint32_t* a = out + (size_t)(1 + k) * N;
+            for (int j = 0; j < N; j += 16) {
+                tfo_chacha20_block(w, seed, TFO_STREAM_BK_MASK, (uint64_t)row * K + k, (uint32_t)(j >> 4));
+                for (int e = 0; e < 16 && j + e < N; e++) a[j + e] = w[e];
+            }
+            /* b += a (*) s_k, negacyclic, s binary */
+            const uint8_t* sk = s_ring + (size_t)k * N;
+            for (int m = 0; m < N; m++) {
+                if (!sk[m]) continue;
+                for (int j = 0; j < N; j++) {
+                    const int idx = j - m;
+                    out[j] += idx < 0 ? 0u - a[idx + N] : a[idx];
+                }
+            }
+        }
+        if (s_lv0[i]) out[(size_t)comp * N] += 1u << (32 - p->bg_bit * (level + 1));
+    }
+}
+
+void tfo_keygen_chacha_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_lv1, const tfo_params* p,
+                          double alpha, const uint32_t seed[8]) {
+    const int n = p->n, T = p->T, bb = p->base_bit;
+    const size_t rows = ((size_t)p->N * p->K * T) << bb;
+    uint32_t w[16];
+    for (size_t row = 0; row < rows; row++) {
+        const int o = (int)(row & ((1u << bb) - 1));
+        uint32_t* out = ks + row * (size_t)(n + 1);
+        if (o == 0) {
+            memset(out, 0, sizeof(uint32_t) * (size_t)(n + 1));
+            continue;
+        }
+        const size_t im = row >> bb;
+        const int m = (int)(im % T);
+        const size_t i = im / T;
+        uint32_t acc = 0;
+        for (int j = 0; j < n; j += 16) {
+            tfo_chacha20_block(w, seed, TFO_STREAM_KS_MASK, (uint64_t)row, (uint32_t)(j >> 4));
+            for (int e = 0; e < 16 && j + e < n; e++) {
+                out[1 + j + e] = w[e];
+                if (s_lv0[j + e]) acc += w[e];
+            }
+        }
+        tfo_chacha20_block(w, seed, TFO_STREAM_KS_NOISE, (uint64_t)row, 0u);
+        double z0, z1;
+        tfo_normal2(w, &z0, &z1);
+        const uint32_t msg = s_lv1[i] ? (uint32_t)o << (32 - (m + 1) * bb) : 0u;
+        out[0] = acc + tfo_torus_from_double(z0 * alpha) + msg;
+    }
+}

@@ -130,6 +130,13 @@ void tfo_trgsw_encrypt_int_poly(uint32_t* trgsw, const int32_t* mu /*[N]*/, cons
                                 const tfo_params* p, tfo_rng* r);
 void tfo_make_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, const tfo_params* p, tfo_rng* r);
 void tfo_make_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_ring, const tfo_params* p, tfo_rng* r);
+/* Restatement of the GPU key generator: same key structure, masks and noise from ChaCha20 under a
+ * 256-bit seed (stream, row and block index in the counter / nonce words). */
+void tfo_chacha20_block(uint32_t out[16], const uint32_t seed[8], uint32_t stream, uint64_t row, uint32_t index);
+void tfo_keygen_chacha_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, const tfo_params* p,
+                          double alpha, const uint32_t seed[8]);
+void tfo_keygen_chacha_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_lv1 /*[N*K]*/, const tfo_params* p,
+                          double alpha, const uint32_t seed[8]);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,8 @@
 // class can be instantiated with a non-default ring.
 #pragma once
 
+#include <array>
+#include <random>
 #include <vector>
 
 #include "gpu_dispatch.hpp"
@@ -63,16 +65,28 @@ public:
     }
 
     // make_evaluate_key with the encryptions done on the GPU (tfhe_amd_keygen): same key structure,
-    // masks and noise from a counter-based generator keyed by `seed`.  Not in the reference, whose
-    // make_evaluate_key takes seconds of host time per key set.
-    EvaluateKey make_evaluate_key_gpu(const SecretKey& secret_key, uint64_t seed) {
+    // masks and noise from ChaCha20 under a 256-bit seed.  Not in the reference, whose
+    // make_evaluate_key takes seconds of host time per key set.  Without a seed argument the seed
+    // comes from the operating system (std::random_device, the reference's source of every word,
+    // src/random.hpp:10): that is the form for real keys.  The 64-bit form is for reproducible tests.
+    EvaluateKey make_evaluate_key_gpu(const SecretKey& secret_key) {
+        std::random_device rd;
+        std::array<uint32_t, 8> seed;
+        for (uint32_t& w : seed) w = rd();
+        return make_evaluate_key_gpu(secret_key, seed);
+    }
+    EvaluateKey make_evaluate_key_gpu(const SecretKey& secret_key, uint64_t test_seed) {
+        return make_evaluate_key_gpu(secret_key, std::array<uint32_t, 8>{static_cast<uint32_t>(test_seed),
+                                                                        static_cast<uint32_t>(test_seed >> 32)});
+    }
+    EvaluateKey make_evaluate_key_gpu(const SecretKey& secret_key, const std::array<uint32_t, 8>& seed) {
         std::vector<uint8_t> s0((size_t)N_LV0), sr((size_t)K * N);
         for (int i = 0; i < N_LV0; i++) s0[i] = secret_key.tlwe_lv0_s[i] ? 1 : 0;
         for (int k = 0; k < K; k++)
             for (int j = 0; j < N; j++) sr[(size_t)k * N + j] = secret_key.trlwe_s[k][j] ? 1 : 0;
         const tfhe_amd_params p = params();
         std::vector<uint32_t> bk(tfhe_amd_bk_words(&p)), ks(tfhe_amd_ks_words(&p));
-        gpu::check(tfhe_amd_keygen(&p, s0.data(), sr.data(), TLWELv0Parameter::ALPHA, TRLWEParameter::ALPHA, seed,
+        gpu::check(tfhe_amd_keygen(&p, s0.data(), sr.data(), TLWELv0Parameter::ALPHA, TRLWEParameter::ALPHA, seed.data(),
                                    gpu::device(), bk.data(), ks.data()),
                    "make_evaluate_key_gpu");
         EvaluateKey ek;

@@ -1,10 +1,13 @@
 """Evaluation-key generation on the GPU (reference HomNAND::make_evaluate_key,
-src/hom_nand.hpp:56-64).  Parity unpinned against reference bytes: the reference draws masks and
-noise from std::random_device (src/random.hpp:10) and cannot be reproduced.  What is checked: the
-generated keys decrypt, under the secret key and with the CPU oracle's phase functions, to exactly
-the messages the reference's make_bk / make_ks encrypt, with noise of the prescribed deviation;
-the result is a pure function of (secret, seed); and gates evaluated with them are correct and
-bit-exact between the GPU and the oracle on the same key bytes."""
+src/hom_nand.hpp:56-64).  The reference draws masks and noise from std::random_device
+(src/random.hpp:10) and cannot be reproduced, so there are no reference bytes to compare with.
+Pinned instead: the GPU keys against the CPU oracle's restatement of the same generator (ChaCha20
+under a 256-bit seed): every mask word identical, every noise word identical or one unit apart (the
+Gaussian goes through log / sin / cos of two different math libraries), at the default and the
+N = 2048 parameter sets.  Also checked: the keys decrypt, under the secret key and with the
+oracle's phase functions, to exactly the messages the reference's make_bk / make_ks encrypt, with
+noise of the prescribed deviation; the result is a pure function of (secret, seed); and gates
+evaluated with them are correct and bit-exact between the GPU and the oracle on the same key bytes."""
 import numpy as np
 import pytest
 
@@ -27,6 +30,42 @@ def generated():
     return p, s0, sr, bk, ks
 
 
+def _compare_with_oracle(p, tp, s0, sr, seed):
+    import tfhe_amd
+
+    bk, ks = tfhe_amd.keygen(tp, s0, sr, p.alpha_lv0, p.alpha_lv1, seed=seed)
+    obk, oks = O.keygen_chacha(s0, sr, p, p.alpha_lv0, p.alpha_lv1, tfhe_amd.seed_words(seed))
+    # masks: pure generator words
+    assert np.array_equal(bk[:, :, 1:, :], obk[:, :, 1:, :])
+    assert np.array_equal(ks[..., 1:], oks[..., 1:])
+    # b words: same masks and messages, so the difference is the difference of the noise words
+    d_bk = (bk[:, :, 0, :] - obk[:, :, 0, :]).view(np.int32)
+    d_ks = (ks[..., 0] - oks[..., 0]).view(np.int32)
+    assert np.abs(d_bk).max() <= 1 and np.abs(d_ks).max() <= 1
+    # ... and all but a vanishing share of them are identical
+    assert np.count_nonzero(d_bk) <= 1e-6 * d_bk.size + 2 and np.count_nonzero(d_ks) <= 1e-6 * d_ks.size + 2
+    return bk, ks
+
+
+def test_keys_equal_the_oracle_generator_default_set(generated):
+    import tfhe_amd
+
+    p, s0, sr, bk, ks = generated
+    bk2, ks2 = _compare_with_oracle(p, tfhe_amd.params_default(), s0, sr, seed=2024)
+    assert np.array_equal(bk, bk2) and np.array_equal(ks, ks2)
+    # a full-width seed: all eight words matter
+    _compare_with_oracle(p, tfhe_amd.params_default(), s0, sr, seed=(1 << 255) | (0xABCDEF << 100) | 7)
+
+
+def test_keys_equal_the_oracle_generator_n2048_set():
+    import tfhe_amd
+
+    p = O.params_n2048()
+    tp = tfhe_amd.Params(p.n, p.N, p.K, p.bg_bit, p.L, p.T, p.base_bit)
+    s0, sr = O.keygen_secret(p, O.rng(8))
+    _compare_with_oracle(p, tp, s0, sr, seed=31337)
+
+
 def test_deterministic_in_the_seed(generated):
     import tfhe_amd
 
@@ -35,6 +74,10 @@ def test_deterministic_in_the_seed(generated):
     assert np.array_equal(bk, bk2) and np.array_equal(ks, ks2)
     bk3, _ = tfhe_amd.keygen(tfhe_amd.params_default(), s0, sr, p.alpha_lv0, p.alpha_lv1, seed=2025, want_ks=False)
     assert _ is None and not np.array_equal(bk, bk3)
+    # seed=None draws the 256 bits from the operating system: two calls never agree
+    bk4, _ = tfhe_amd.keygen(tfhe_amd.params_default(), s0, sr, p.alpha_lv0, p.alpha_lv1, seed=None, want_ks=False)
+    bk5, _ = tfhe_amd.keygen(tfhe_amd.params_default(), s0, sr, p.alpha_lv0, p.alpha_lv1, seed=None, want_ks=False)
+    assert not np.array_equal(bk4[0, 0, 1], bk5[0, 0, 1])
 
 
 def test_bootstrapping_key_rows_encrypt_the_gadget(generated):

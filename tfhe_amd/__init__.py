@@ -5,4 +5,4 @@ used by the tests and the benchmark.  There is no CPU fallback: importing works 
 the library, but every operation raises if it is missing.
 """
 from .binding import (Context, MultiContext, Params, TfheAmdError, cmux, external_product, lib_path, library,  # noqa: F401
-                      keygen, load_error, params_default, version)
+                      keygen, load_error, params_default, seed_words, version)

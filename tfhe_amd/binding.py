@@ -84,9 +84,9 @@ def library():
     lib.tfhe_amd_ks_words.argtypes = [pp]
     lib.tfhe_amd_ks_words.restype = sz
     lib.tfhe_amd_ctx_create.argtypes = [pp, vp, vp, i32, C.c_uint, C.POINTER(vp)]
-    lib.tfhe_amd_keygen.argtypes = [pp, vp, vp, C.c_double, C.c_double, C.c_uint64, i32, vp, vp]
-    lib.tfhe_amd_keygen_device.argtypes = [pp, vp, vp, C.c_double, C.c_double, C.c_uint64, i32, vp, vp, vp]
-    lib.tfhe_amd_ctx_create_from_secret.argtypes = [pp, vp, vp, C.c_double, C.c_double, C.c_uint64, i32, C.c_uint,
+    lib.tfhe_amd_keygen.argtypes = [pp, vp, vp, C.c_double, C.c_double, vp, i32, vp, vp]
+    lib.tfhe_amd_keygen_device.argtypes = [pp, vp, vp, C.c_double, C.c_double, vp, i32, vp, vp, vp]
+    lib.tfhe_amd_ctx_create_from_secret.argtypes = [pp, vp, vp, C.c_double, C.c_double, vp, i32, C.c_uint,
                                                     C.POINTER(vp)]
     lib.tfhe_amd_ctx_destroy.argtypes = [vp]
     lib.tfhe_amd_ctx_destroy.restype = None
@@ -221,9 +221,10 @@ class Context:
         self = cls.__new__(cls)
         self.params, self.device, self._h = params, int(device), C.c_void_p()
         flags = {None: 0, 'latency': cls.LATENCY_FORM, 'throughput': cls.THROUGHPUT_FORM}[form]
+        sw = seed_words(seed)
         _check(library().tfhe_amd_ctx_create_from_secret(
             C.byref(params), s0.ctypes.data_as(C.c_void_p), sr.ctypes.data_as(C.c_void_p), float(alpha_lv0),
-            float(alpha_lv1), int(seed), self.device, flags, C.byref(self._h)))
+            float(alpha_lv1), sw.ctypes.data_as(C.c_void_p), self.device, flags, C.byref(self._h)))
         return self
 
     def close(self):
@@ -543,6 +544,25 @@ class MultiContext:
         _check(library().tfhe_amd_multi_ctx_synchronize(self._h))
 
 
+def seed_words(seed):
+    """The 256-bit key-generation seed as eight uint32 words: None = fresh OS entropy (what a real
+    key needs); an int (little endian, for reproducible tests); 32 bytes; or eight words."""
+    if seed is None:
+        seed = os.urandom(32)
+    if isinstance(seed, int):
+        if seed < 0 or seed >> 256:
+            raise ValueError("the seed is a 256-bit unsigned number")
+        seed = seed.to_bytes(32, "little")
+    if isinstance(seed, (bytes, bytearray)):
+        if len(seed) != 32:
+            raise ValueError("the seed is 32 bytes")
+        return np.frombuffer(bytes(seed), dtype="<u4").astype(np.uint32)
+    w = np.ascontiguousarray(seed, dtype=np.uint32).reshape(-1)
+    if w.size != 8:
+        raise ValueError("the seed is eight 32-bit words")
+    return w
+
+
 def _secret_bytes(params, s_lv0, s_ring):
     s0 = np.ascontiguousarray(s_lv0, dtype=np.uint8).reshape(-1)
     sr = np.ascontiguousarray(s_ring, dtype=np.uint8).reshape(-1)
@@ -555,12 +575,14 @@ def _secret_bytes(params, s_lv0, s_ring):
 
 def keygen(params, s_lv0, s_ring, alpha_lv0, alpha_lv1, seed, device=0, want_bk=True, want_ks=True):
     """(bk, ks) as host arrays, generated on the GPU (reference src/trgsw.hpp:119-129,
-    src/tlwe_key_switching.hpp:26-45).  A key that is not wanted comes back as None."""
+    src/tlwe_key_switching.hpp:26-45).  seed: see seed_words (None = OS entropy).  A key that is
+    not wanted comes back as None."""
     s0, sr = _secret_bytes(params, s_lv0, s_ring)
     bk = np.empty(params.bk_shape(), dtype=np.uint32) if want_bk else None
     ks = np.empty(params.ks_shape(), dtype=np.uint32) if want_ks else None
+    sw = seed_words(seed)
     _check(library().tfhe_amd_keygen(C.byref(params), s0.ctypes.data_as(C.c_void_p), sr.ctypes.data_as(C.c_void_p),
-                                     float(alpha_lv0), float(alpha_lv1), int(seed), int(device),
+                                     float(alpha_lv0), float(alpha_lv1), sw.ctypes.data_as(C.c_void_p), int(device),
                                      bk.ctypes.data_as(C.c_void_p) if want_bk else None,
                                      ks.ctypes.data_as(C.c_void_p) if want_ks else None))
     return bk, ks

@@ -737,9 +737,12 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
 }
 
 int tfhe_amd_keygen_device(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
-                           double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks, void* stream) {
+                           double alpha_lv1, const uint32_t* seed, int device, uint32_t* bk, uint32_t* ks, void* stream) {
     if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
     if (!s_lv0 || !s_ring) return fail(TFHE_AMD_ERR_ARGUMENT, "null secret key");
+    if (!seed) return fail(TFHE_AMD_ERR_ARGUMENT, "null seed");
+    KeygenSeed key;
+    std::memcpy(key.w, seed, sizeof(key.w));
     if (!bk && !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "both key pointers are null");
     if (!(alpha_lv0 >= 0.0 && alpha_lv0 < 0.5 && alpha_lv1 >= 0.0 && alpha_lv1 < 0.5))
         return fail(TFHE_AMD_ERR_ARGUMENT, "noise parameters must lie in [0, 0.5)");
@@ -758,16 +761,16 @@ int tfhe_amd_keygen_device(const tfhe_amd_params* p, const uint8_t* s_lv0, const
     HIP_TRY(hipMemcpyAsync(d_sr.p, s_ring, ring, hipMemcpyHostToDevice, s));
     if (bk)
         HIP_TRY(launch_keygen_bk(bk, d_s0.as<uint8_t>(), d_sr.as<uint8_t>(), p->n, p->N, p->K, p->L, p->bg_bit, alpha_lv1,
-                                 seed, s));
+                                 key, s));
     if (ks)
         HIP_TRY(launch_keygen_ks(ks, d_s0.as<uint8_t>(), d_sr.as<uint8_t>(), p->n, p->N * p->K, p->T, p->base_bit,
-                                 alpha_lv0, seed, s));
+                                 alpha_lv0, key, s));
     HIP_TRY(hipStreamSynchronize(s));  // the secret-key copies are freed on return
     return TFHE_AMD_OK;
 }
 
 int tfhe_amd_keygen(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring, double alpha_lv0,
-                    double alpha_lv1, uint64_t seed, int device, uint32_t* bk, uint32_t* ks) {
+                    double alpha_lv1, const uint32_t* seed, int device, uint32_t* bk, uint32_t* ks) {
     if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
     if (!bk && !ks) return fail(TFHE_AMD_ERR_ARGUMENT, "both key pointers are null");
     int ndev = 0;
@@ -788,7 +791,7 @@ int tfhe_amd_keygen(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_
 }
 
 int tfhe_amd_ctx_create_from_secret(const tfhe_amd_params* p, const uint8_t* s_lv0, const uint8_t* s_ring,
-                                    double alpha_lv0, double alpha_lv1, uint64_t seed, int device, unsigned flags,
+                                    double alpha_lv0, double alpha_lv1, const uint32_t* seed, int device, unsigned flags,
                                     tfhe_amd_ctx** out) {
     if (!out) return fail(TFHE_AMD_ERR_ARGUMENT, "out is null");
     *out = nullptr;

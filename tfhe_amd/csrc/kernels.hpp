@@ -36,10 +36,11 @@ hipError_t launch_blind_rotate_replica(const d2* spec, const d2* tables, const u
                                        uint32_t* out, size_t n_gates, int n, int N, int K, int L, int bg, int extract,
                                        int generic, hipStream_t stream);
 // evaluation-key generation (keygen_kernels.hip): raw keys in the flat layouts of tfhe_amd.h, device memory
+struct KeygenSeed { uint32_t w[8]; };  // the 256-bit ChaCha20 key that every mask and noise word derives from
 hipError_t launch_keygen_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, int n, int N, int K, int L,
-                            int bg_bit, double alpha, uint64_t seed, hipStream_t stream);
+                            int bg_bit, double alpha, const KeygenSeed& seed, hipStream_t stream);
 hipError_t launch_keygen_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_lv1, int n, int nlv1, int T, int bb,
-                            double alpha, uint64_t seed, hipStream_t stream);
+                            double alpha, const KeygenSeed& seed, hipStream_t stream);
 // exact O(N^2) kernels for any parameter set (generic_kernels.hip)
 bool generic_has_kernel(int N, int K, int L);
 hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,

@@ -4,43 +4,50 @@
 // src/tlwe.hpp:55-61) in the flat layouts of include/tfhe_amd.h.
 //
 // Randomness: the reference draws masks and noise from std::random_device (src/random.hpp:10) and
-// cannot be reproduced; here every word comes from Philox-4x32-10 keyed by the caller's seed and
-// counted by (stream, row, index), so a key set is a pure function of (secret key, seed) whatever
-// the launch geometry.  Distributions follow the reference: uniform 32-bit masks
+// cannot be reproduced; here every word comes from the ChaCha20 block function keyed by the
+// caller's 256-bit seed, with the block position (block index, stream, row) in the counter and
+// nonce words, so a key set is a pure function of (secret key, seed) whatever the launch geometry,
+// and as unpredictable as the seed is.  Distributions follow the reference: uniform 32-bit masks
 // (src/random.hpp:39-41), Gaussian noise of standard deviation alpha converted to the torus with
 // the truncating double -> torus rule (src/types.hpp:28-33).
 #include "kernels.hpp"
 
 namespace tfhe_amd {
 
-struct Philox {
-    uint32_t k0, k1;
-    __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t a, uint32_t b) const {
-        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-        const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-        const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-        const uint32_t n0 = hi1 ^ c[1] ^ a, n1 = lo1, n2 = hi0 ^ c[3] ^ b, n3 = lo0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    }
-    // four words for counter (c0, c1, c2, c3)
-    __device__ __forceinline__ void block(uint32_t (&c)[4]) const {
-        uint32_t a = k0, b = k1;
-#pragma unroll
-        for (int r = 0; r < 10; r++) {
-            round(c, a, b);
-            a += 0x9E3779B9u;
-            b += 0xBB67AE85u;
-        }
-    }
-};
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
 
-// counter layout: (index, row low, row high, stream)
+#define TFHE_AMD_CHACHA_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); \
+    c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  \
+    c += d; b ^= c; b = rotl32(b, 7);
+
+// streams: which part of the key set a block belongs to
 enum : uint32_t { kStreamBkMask = 1, kStreamBkNoise = 2, kStreamKsMask = 3, kStreamKsNoise = 4 };
 
-__device__ __forceinline__ void philox4(uint32_t (&out)[4], uint64_t seed, uint32_t stream, uint64_t row, uint32_t index) {
-    Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32)};
-    out[0] = index; out[1] = (uint32_t)row; out[2] = (uint32_t)(row >> 32); out[3] = stream;
-    ph.block(out);
+// One ChaCha20 block (RFC 8439 block function: 20 rounds, feed-forward): state = constants | key[8] |
+// (index, stream, row low, row high).  16 output words.
+__device__ __forceinline__ void chacha20_block(uint32_t (&out)[16], const KeygenSeed& seed, uint32_t stream, uint64_t row,
+                                               uint32_t index) {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                       seed.w[0], seed.w[1], seed.w[2], seed.w[3], seed.w[4], seed.w[5], seed.w[6], seed.w[7],
+                       index, stream, (uint32_t)row, (uint32_t)(row >> 32)};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = in[i];
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        TFHE_AMD_CHACHA_QR(x[0], x[4], x[8], x[12])
+        TFHE_AMD_CHACHA_QR(x[1], x[5], x[9], x[13])
+        TFHE_AMD_CHACHA_QR(x[2], x[6], x[10], x[14])
+        TFHE_AMD_CHACHA_QR(x[3], x[7], x[11], x[15])
+        TFHE_AMD_CHACHA_QR(x[0], x[5], x[10], x[15])
+        TFHE_AMD_CHACHA_QR(x[1], x[6], x[11], x[12])
+        TFHE_AMD_CHACHA_QR(x[2], x[7], x[8], x[13])
+        TFHE_AMD_CHACHA_QR(x[3], x[4], x[9], x[14])
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
 }
 
 // reference src/types.hpp:28-33: fmod, +1 if negative, times 2^32, truncate
@@ -51,7 +58,7 @@ __device__ __forceinline__ uint32_t torus_from_double(double d) {
 }
 
 // two standard normals from four words (Box-Muller on 53- and 52-bit uniforms)
-__device__ __forceinline__ void normal2(const uint32_t (&w)[4], double& z0, double& z1) {
+__device__ __forceinline__ void normal2(const uint32_t* w, double& z0, double& z1) {
     const double u1 = ((double)(((uint64_t)w[0] << 21) ^ (w[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);  // (0, 1]
     const double u2 = (double)(((uint64_t)w[2] << 20) ^ (w[3] >> 12)) * (1.0 / 4503599627370496.0);        // [0, 1)
     const double r = sqrt(-2.0 * log(u1));
@@ -64,10 +71,12 @@ __device__ __forceinline__ void normal2(const uint32_t (&w)[4], double& z0, doub
 // One workgroup per TRLWE row of the bootstrapping key: row id = i * R + r, r = comp * L + level.
 // Output: bk[row][c][N], c = 0 the b polynomial, c = 1..K the mask polynomials.
 // b = e + sum_k a_k (*) s_k (negacyclic, s binary), then s0_i * 2^(32 - bg (level + 1)) is added to
-// coefficient 0 of polynomial `comp`.
+// coefficient 0 of polynomial `comp`.  Word j of mask polynomial k is word j % 16 of block j / 16 of
+// (stream mask, row * K + k); noise coefficient j is normal j % 2 of the Box-Muller pair made from
+// words 4 (j / 2 % 4) .. + 3 of block j / 8 of (stream noise, row).
 __global__ void __launch_bounds__(256)
 keygen_bk_kernel(uint32_t* __restrict__ bk, const uint8_t* __restrict__ s_lv0, const uint8_t* __restrict__ s_ring,
-                 int N, int K, int L, int bg_bit, double alpha, uint64_t seed) {
+                 int N, int K, int L, int bg_bit, double alpha, const KeygenSeed seed) {
     extern __shared__ uint32_t s_mem[];  // a[N] | s bits as words [N]
     uint32_t* s_a = s_mem;
     uint32_t* s_s = s_mem + N;
@@ -77,22 +86,25 @@ keygen_bk_kernel(uint32_t* __restrict__ bk, const uint8_t* __restrict__ s_lv0, c
     uint32_t* out = bk + row * (size_t)K1 * N;
     const int t = threadIdx.x, T = blockDim.x;
 
-    // noise into b (two normals per Philox block)
-    for (int j = 2 * t; j < N; j += 2 * T) {
-        uint32_t w[4];
-        philox4(w, seed, kStreamBkNoise, row, (uint32_t)(j >> 1));
-        double z0, z1;
-        normal2(w, z0, z1);
-        out[j] = torus_from_double(z0 * alpha);
-        if (j + 1 < N) out[j + 1] = torus_from_double(z1 * alpha);
+    // noise into b (eight normals per block)
+    for (int j = 8 * t; j < N; j += 8 * T) {
+        uint32_t w[16];
+        chacha20_block(w, seed, kStreamBkNoise, row, (uint32_t)(j >> 3));
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            double z0, z1;
+            normal2(w + 4 * e, z0, z1);
+            if (j + 2 * e < N) out[j + 2 * e] = torus_from_double(z0 * alpha);
+            if (j + 2 * e + 1 < N) out[j + 2 * e + 1] = torus_from_double(z1 * alpha);
+        }
     }
     for (int k = 0; k < K; k++) {
         __syncthreads();
-        for (int j = 4 * t; j < N; j += 4 * T) {
-            uint32_t w[4];
-            philox4(w, seed, kStreamBkMask, row * (uint64_t)K + k, (uint32_t)(j >> 2));
+        for (int j = 16 * t; j < N; j += 16 * T) {
+            uint32_t w[16];
+            chacha20_block(w, seed, kStreamBkMask, row * (uint64_t)K + k, (uint32_t)(j >> 4));
 #pragma unroll
-            for (int e = 0; e < 4; e++)
+            for (int e = 0; e < 16; e++)
                 if (j + e < N) {
                     s_a[j + e] = w[e];
                     out[(size_t)(1 + k) * N + j + e] = w[e];
@@ -118,10 +130,11 @@ keygen_bk_kernel(uint32_t* __restrict__ bk, const uint8_t* __restrict__ s_lv0, c
 
 // One wave per row (i, m, o) with o >= 1 of the key-switching key; rows with o = 0 stay zero (the
 // reference never writes or reads them).  row = [b, a_0 .. a_{n-1}],
-// b = e + sum_j a_j s0_j + o * s1_i * 2^(32 - bb (m + 1)).
+// b = e + sum_j a_j s0_j + o * s1_i * 2^(32 - bb (m + 1)).  Mask word j is word j % 16 of block j / 16
+// of (stream mask, row); the noise is the first normal of block 0 of (stream noise, row).
 __global__ void __launch_bounds__(256)
 keygen_ks_kernel(uint32_t* __restrict__ ks, const uint8_t* __restrict__ s_lv0, const uint8_t* __restrict__ s_lv1,
-                 size_t n_rows, int n, int T, int bb, double alpha, uint64_t seed) {
+                 size_t n_rows, int n, int T, int bb, double alpha, const KeygenSeed seed) {
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -135,22 +148,24 @@ keygen_ks_kernel(uint32_t* __restrict__ ks, const uint8_t* __restrict__ s_lv0, c
     const int m = (int)(im % T);
     const size_t i = im / T;
     uint32_t acc = 0;
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        const int j = j0 + 4 * lane;
-        uint32_t w[4];
-        philox4(w, seed, kStreamKsMask, row, (uint32_t)(j >> 2));
+    for (int j0 = 0; j0 < n; j0 += 1024) {
+        const int j = j0 + 16 * lane;
+        if (j < n) {
+            uint32_t w[16];
+            chacha20_block(w, seed, kStreamKsMask, row, (uint32_t)(j >> 4));
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (j + e < n) {
-                out[1 + j + e] = w[e];
-                if (s_lv0[j + e]) acc += w[e];
-            }
+            for (int e = 0; e < 16; e++)
+                if (j + e < n) {
+                    out[1 + j + e] = w[e];
+                    if (s_lv0[j + e]) acc += w[e];
+                }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) {
-        uint32_t w[4];
-        philox4(w, seed, kStreamKsNoise, row, 0u);
+        uint32_t w[16];
+        chacha20_block(w, seed, kStreamKsNoise, row, 0u);
         double z0, z1;
         normal2(w, z0, z1);
         const uint32_t msg = s_lv1[i] ? (uint32_t)o << (32 - (m + 1) * bb) : 0u;
@@ -159,7 +174,7 @@ keygen_ks_kernel(uint32_t* __restrict__ ks, const uint8_t* __restrict__ s_lv0, c
 }
 
 hipError_t launch_keygen_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s_ring, int n, int N, int K, int L,
-                            int bg_bit, double alpha, uint64_t seed, hipStream_t stream) {
+                            int bg_bit, double alpha, const KeygenSeed& seed, hipStream_t stream) {
     const size_t rows = (size_t)n * (K + 1) * L;
     if (rows == 0) return hipSuccess;
     const int threads = N >= 256 ? 256 : 64;
@@ -169,7 +184,7 @@ hipError_t launch_keygen_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s
 }
 
 hipError_t launch_keygen_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_lv1, int n, int nlv1, int T, int bb,
-                            double alpha, uint64_t seed, hipStream_t stream) {
+                            double alpha, const KeygenSeed& seed, hipStream_t stream) {
     const size_t rows = (size_t)nlv1 * T << bb;
     if (rows == 0) return hipSuccess;
     keygen_ks_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, stream>>>(ks, s_lv0, s_lv1, rows, n, T, bb, alpha, seed);
