@@ -214,7 +214,7 @@ static inline uint32_t g_to_torus(uint64_t v) {
  * pointwise product, the same FFT with the omega table reversed from index 1, scale by 1/M, untwist,
  * and convert each part with the truncating double -> torus rule.  Every floating-point operation
  * is a plain IEEE double multiply, add or subtract in the reference's order (complex products as
- * (ac - bd, ad + bc)); libm's cos and sin give the same table as std::polar on the same machine.
+ * (ac - bd, ad + bc)); the three std::polar values the tables start from are constants (kUnitRoot).
  * Build without -ffast-math and without FMA contraction (the oracle's Makefile does). */
 typedef struct { double re, im; } cplx;
 static inline cplx c_mul(cplx x, cplx y) {
@@ -222,7 +222,26 @@ static inline cplx c_mul(cplx x, cplx y) {
     cplx r = { ac - bd, ad + bc };
     return r;
 }
-static inline cplx c_polar(double theta) { cplx r = { 1.0 * cos(theta), 1.0 * sin(theta) }; return r; }
+/* cos and sin of pi / 2^j for j = 3 .. 11, correctly rounded (computed in 80-digit arithmetic from the
+ * double nearest to pi / 2^j; x86-64 glibc, whose std::polar the reference's recorded outputs come from,
+ * returns the same values).  The power tables of the reference's FFT product (reference
+ * src/types.hpp:257-268,276-283) start from these, so they do not depend on the math library of
+ * the machine that runs this code. */
+static const double kUnitRoot[9][2] = {
+    {0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2},  {0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60ap-3},
+    {0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4},  {0x1.ff621e3796d7ep-1, 0x1.91f65f10dd814p-5},
+    {0x1.ffd886084cd0dp-1, 0x1.92155f7a3667ep-6},  {0x1.fff62169b92dbp-1, 0x1.921d1fcdec784p-7},
+    {0x1.fffd8858e8a92p-1, 0x1.921f0fe670071p-8},  {0x1.ffff621621d02p-1, 0x1.921f8becca4bap-9},
+    {0x1.ffffd88586ee6p-1, 0x1.921faaee6472dp-10}};
+
+/* std::polar(1.0, sign * pi / 2^j) */
+static inline cplx c_polar_pow2(int j, int sign) {
+    cplx r;
+    if (j >= 3 && j <= 11) { r.re = kUnitRoot[j - 3][0]; r.im = sign * kUnitRoot[j - 3][1]; }
+    else { const double theta = sign * M_PI / (double)(1u << j); r.re = 1.0 * cos(theta); r.im = 1.0 * sin(theta); }
+    return r;
+}
+static inline int log2_exact(int v) { int b = 0; while ((1 << b) < v) b++; return b; }
 
 static void ref_fft(cplx* a, cplx* tmp, int M, const cplx* omega_pow) {
     int bits = 0;
@@ -264,14 +283,14 @@ static void reference_fft_mul(uint32_t* out, const int32_t* d, const uint32_t* b
         rhs[i].re = (double)b[i] / 4294967296.0;       /* operator double: raw / 2^32 */
         rhs[i].im = (double)b[i + M] / 4294967296.0;
     }
-    const cplx w = c_polar(M_PI / (M * 2));
+    const cplx w = c_polar_pow2(log2_exact(M) + 1, 1);         /* M_PI / (M * 2) */
     cplx w_pow = { 1.0, 0.0 };
     for (int i = 0; i < M; i++) {
         lhs[i] = c_mul(lhs[i], w_pow);
         rhs[i] = c_mul(rhs[i], w_pow);
         w_pow = c_mul(w_pow, w);
     }
-    const cplx omega = c_polar(-M_PI * 2 / M);
+    const cplx omega = c_polar_pow2(log2_exact(M) - 1, -1);    /* -M_PI * 2 / M */
     omega_pow[0].re = 1.0; omega_pow[0].im = 0.0;
     for (int i = 0; i < M - 1; i++) omega_pow[i + 1] = c_mul(omega_pow[i], omega);
     ref_fft(lhs, tmp, M, omega_pow);
@@ -279,7 +298,7 @@ static void reference_fft_mul(uint32_t* out, const int32_t* d, const uint32_t* b
     for (int i = 0; i < M; i++) prod[i] = c_mul(lhs[i], rhs[i]);
     for (int i = 1, j = M - 1; i < j; i++, j--) { cplx t = omega_pow[i]; omega_pow[i] = omega_pow[j]; omega_pow[j] = t; }
     ref_fft(prod, tmp, M, omega_pow);
-    const cplx w_inv = c_polar(-M_PI / (M * 2));
+    const cplx w_inv = c_polar_pow2(log2_exact(M) + 1, -1);    /* -M_PI / (M * 2) */
     cplx w_inv_pow = { 1.0, 0.0 };
     const double scale = 1. / M;
     for (int i = 0; i < M; i++) {
@@ -702,15 +721,14 @@ uint64_t tfo_rng_u64(tfo_rng* r) {
 
 static inline double rng_unit(tfo_rng* r) { return (double)(tfo_rng_u64(r) >> 11) * (1.0 / 9007199254740992.0); }
 
+/* Approximately standard normal, from additions only: the sum of twelve uniforms minus six
+ * (Irwin-Hall; mean 0, variance 1, support [-6, 6]).  No logarithm or trigonometric function, so the
+ * seeded key generator returns the same bytes on every machine, whatever its math library -- the
+ * recorded known answers of the compiled reference (tests/golden/refnand512.npz) depend on that. */
 double tfo_rng_normal(tfo_rng* r) {
-    if (r->has_spare) { r->has_spare = 0; return r->spare; }
-    double u1;
-    do { u1 = rng_unit(r); } while (u1 <= 0.0);
-    const double u2 = rng_unit(r);
-    const double m = sqrt(-2.0 * log(u1));
-    r->spare = m * sin(6.283185307179586 * u2);
-    r->has_spare = 1;
-    return m * cos(6.283185307179586 * u2);
+    double s = 0.0;
+    for (int i = 0; i < 12; i++) s += rng_unit(r);
+    return s - 6.0;
 }
 
 /* reference src/types.hpp:28-33 */

@@ -260,11 +260,14 @@ def test_mux_adder_32_bits_on_device(keys, ctx, octx):
 # ---- the 65,536-gate configuration at full size on one GPU ---------------------------------------
 
 def test_config3_65536_gates_decrypt_and_sampled_parity(keys, ctx, octx):
-    """All 65,536 outputs decrypt to NAND of the inputs; 48 gates spread over the batch (first and
-    last workgroups included) are bit-exact with the oracle."""
+    """All 65,536 outputs decrypt to NAND of the inputs; every output word equals what an independent
+    kernel returns for the same gates (the workgroup-per-gate form, run in 128 chunks of 512 gates and
+    compared on the GPU); 512 gates, one per stride of 128 at a moving offset plus the first and last
+    eight, are bit-exact with the oracle."""
+    import tfhe_amd
     import torch
 
-    p, s0, _, _, _ = keys
+    p, s0, _, bk, ks = keys
     G = 65536
     rs = np.random.RandomState(2)
     ba, bb = rs.randint(0, 2, G), rs.randint(0, 2, G)
@@ -278,7 +281,15 @@ def test_config3_65536_gates_decrypt_and_sampled_parity(keys, ctx, octx):
     s = s0.astype(np.uint32)
     phase = got[:, 0] - (got[:, 1:] * s[None, :]).sum(axis=1, dtype=np.uint32)
     assert np.array_equal((phase >> 31) == 0, (1 - (ba & bb)).astype(bool))
-    pick = np.unique(np.concatenate([np.arange(0, 8), np.arange(G - 8, G), rs.randint(0, G, 32)]))
+    # the whole batch against the other blind-rotation form (different kernel, different work split)
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks, form="latency") as lat:
+        chunk = torch.empty((512, p.n + 1), dtype=torch.int32, device="cuda")
+        for lo in range(0, G, 512):
+            lat.nand_device(da[lo:lo + 512], db[lo:lo + 512], chunk)
+            assert torch.equal(chunk, out[lo:lo + 512]), f"gates {lo}..{lo + 511} differ between the two kernel forms"
+    pick = np.unique(np.concatenate([np.arange(0, 8), np.arange(G - 8, G),
+                                     np.arange(0, G, 128) + (np.arange(G // 128) * 37) % 128]))
+    assert pick.size >= 512
     assert np.array_equal(got[pick], octx.nand_batch(a[pick], b[pick]))
 
 

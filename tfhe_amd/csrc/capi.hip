@@ -216,11 +216,23 @@ std::vector<double> build_tw_block_512(const TwiddleSet& t) {
     return blk;
 }
 
+/* cos and sin of pi / 2^j for j = 3 .. 11, correctly rounded (computed in 80-digit arithmetic from the
+ * double nearest to pi / 2^j; x86-64 glibc, whose std::polar the reference's recorded outputs come from,
+ * returns the same values).  The power tables of the reference's FFT product (reference
+ * src/types.hpp:257-268,276-283) start from these, so they do not depend on the math library of
+ * the machine that runs this code. */
+const double kUnitRoot[9][2] = {
+    {0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2},  {0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60ap-3},
+    {0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4},  {0x1.ff621e3796d7ep-1, 0x1.91f65f10dd814p-5},
+    {0x1.ffd886084cd0dp-1, 0x1.92155f7a3667ep-6},  {0x1.fff62169b92dbp-1, 0x1.921d1fcdec784p-7},
+    {0x1.fffd8858e8a92p-1, 0x1.921f0fe670071p-8},  {0x1.ffff621621d02p-1, 0x1.921f8becca4bap-9},
+    {0x1.ffffd88586ee6p-1, 0x1.921faaee6472dp-10}};
+
 // Power tables of the reference's FFT product for ring degree N (M = N / 2), as the reference builds
 // them (src/types.hpp:257-268,276-283): [0] twist powers w^i, w = e^(i pi / N), by repeated
 // multiplication; [1] omega^i, omega = e^(-2 pi i / M), by repeated multiplication; [2] untwist
-// powers; [3] the omega table with entries 1 .. M-1 reversed.  cos and sin are libm's, as in
-// std::polar; the arguments are volatile so that they are evaluated at run time by that libm.
+// powers; [3] the omega table with entries 1 .. M-1 reversed.  The three starting values are what
+// std::polar returns for angles pi / 2^j (kUnitRoot; libm outside its range).
 std::vector<double> build_replica_tables(int N) {
     const int M = N / 2;
     std::vector<double> t((size_t)4 * M * 2);
@@ -229,14 +241,22 @@ std::vector<double> build_replica_tables(int N) {
         rr = ac - bd;
         ri = ad + bc;
     };
-    auto polar = [](double theta, double& r, double& i) {
-        volatile double th = theta;
-        r = 1.0 * std::cos(th);
-        i = 1.0 * std::sin(th);
+    // std::polar(1.0, sign * pi / 2^j)
+    auto polar = [](int j, int sign, double& r, double& i) {
+        if (j >= 3 && j <= 11) {
+            r = kUnitRoot[j - 3][0];
+            i = sign * kUnitRoot[j - 3][1];
+        } else {
+            volatile double th = sign * M_PI / (double)(1u << j);
+            r = 1.0 * std::cos(th);
+            i = 1.0 * std::sin(th);
+        }
     };
-    auto fill_powers = [&](int section, double theta) {
+    int logM = 0;
+    while ((1 << logM) < M) logM++;
+    auto fill_powers = [&](int section, int j, int sign) {
         double wr, wi, pr = 1.0, pi = 0.0;
-        polar(theta, wr, wi);
+        polar(j, sign, wr, wi);
         for (int i = 0; i < M; i++) {
             t[((size_t)section * M + i) * 2] = pr;
             t[((size_t)section * M + i) * 2 + 1] = pi;
@@ -246,9 +266,9 @@ std::vector<double> build_replica_tables(int N) {
             pi = ni;
         }
     };
-    fill_powers(0, M_PI / (M * 2));
-    fill_powers(1, -M_PI * 2 / M);
-    fill_powers(2, -M_PI / (M * 2));
+    fill_powers(0, logM + 1, 1);   // M_PI / (M * 2)
+    fill_powers(1, logM - 1, -1);  // -M_PI * 2 / M
+    fill_powers(2, logM + 1, -1);  // -M_PI / (M * 2)
     for (int i = 0; i < M; i++) {
         const int src = i == 0 ? 0 : M - i;
         t[((size_t)3 * M + i) * 2] = t[((size_t)1 * M + src) * 2];
