@@ -133,6 +133,11 @@ constexpr bool kPinThroughput = TFHE_AMD_PIN_THROUGHPUT != 0;
 #ifndef TFHE_AMD_PAIR_THROUGHPUT
 #define TFHE_AMD_PAIR_THROUGHPUT 1
 #endif
+// Counter experiment (wrong results): 1 = the rotated accumulator reads of the throughput form
+// become aligned ones, to see which share of the LDS bank conflicts they cause.
+#ifndef TFHE_AMD_EXPERIMENT_ALIGNED_ACC
+#define TFHE_AMD_EXPERIMENT_ALIGNED_ACC 0
+#endif
 
 template <int K, int L>
 __global__ void __launch_bounds__(256, 2)
@@ -213,7 +218,7 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
             uint32_t t[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const uint32_t v = acc[q][src[k]];
+                const uint32_t v = acc[q][TFHE_AMD_EXPERIMENT_ALIGNED_ACC ? 64 * k + lane : src[k]];
                 t[k] = ((((v ^ neg[k]) - neg[k]) - acc[q][64 * k + lane]) + offset) ^ flip;
             }
 #if TFHE_AMD_PAIR_THROUGHPUT
