@@ -55,7 +55,9 @@ typedef struct tfhe_amd_ctx tfhe_amd_ctx;
 
 /* `stream` arguments of the _device entry points: NULL = the context's own (non-blocking)
  * stream; TFHE_AMD_DEFAULT_STREAM = the device's default (null) stream, whose handle is itself
- * NULL and therefore needs a name of its own; anything else = a hipStream_t. */
+ * NULL and therefore needs a name of its own; anything else = a hipStream_t.  A call is ordered
+ * only against work on the stream it is given: pass the stream that produces the input arrays, or
+ * synchronise that stream before calling on another one. */
 #define TFHE_AMD_DEFAULT_STREAM ((void*)(intptr_t)-1)
 
 /* Fills *p with the reference's default parameter set. */
@@ -67,7 +69,9 @@ size_t tfhe_amd_ks_words(const tfhe_amd_params* p);
 
 enum {
     TFHE_AMD_CTX_DEFAULT = 0,
-    TFHE_AMD_CTX_KEYS_ON_DEVICE = 1,  /* bk / ks point to memory of GPU `device` (e.g. after a broadcast) */
+    TFHE_AMD_CTX_KEYS_ON_DEVICE = 1,  /* bk / ks point to memory of GPU `device` (e.g. after a broadcast).  The
+                                         context reads them on a stream of its own: whatever wrote them
+                                         must have finished (synchronise the producing stream first) */
     TFHE_AMD_CTX_GENERIC_KERNELS = 2, /* use the parameter-generic exact O(N^2) kernels even where a
                                          specialised NTT kernel exists (cross-checking) */
     /* The specialised blind rotation has two forms with identical results: one gate per wave
