@@ -212,7 +212,10 @@ int tfhe_amd_identity_key_switch_batch_device(tfhe_amd_ctx* ctx, const uint32_t*
 
 /* TRGSW::external_product / TRGSW::cmux on explicit operands (reference src/trgsw.hpp:100-117),
  * no context: trgsw [batch][(K+1)L][K+1][N], TRLWE operands and out [batch][K+1][N], all in HOST
- * memory; evaluated on GPU `device`.  cmux: out = trgsw (x) (d1 - d0) + d0. */
+ * memory; evaluated on GPU `device`.  cmux: out = trgsw (x) (d1 - d0) + d0.  Parameter sets with NTT
+ * kernels (tfhe_amd_ctx_kernel_family) transform the samples and multiply in the NTT domain, the
+ * others use the exact O(N^2) kernels.  Staging buffers and tables are kept per device for the life
+ * of the process; calls on one device run one at a time. */
 int tfhe_amd_external_product_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* trlwe,
                                     uint32_t* out, size_t batch, int device);
 int tfhe_amd_cmux_batch(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* d0, const uint32_t* d1,

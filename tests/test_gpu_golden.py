@@ -247,3 +247,28 @@ def test_config5_n2048_nand_vs_oracle():
         got = ctx.nand(a, b)
     assert np.array_equal(got, want)
     assert np.array_equal(O.decrypt_bits(got, s0, op), 1 - (bits_a & bits_b))
+
+
+@pytest.mark.parametrize("N,K,L", [(512, 2, 2), (512, 1, 2), (512, 2, 3), (1024, 1, 2), (1024, 2, 2), (2048, 1, 3)])
+def test_stand_alone_external_product_and_cmux_on_ntt_kernels(N, K, L):
+    """tfhe_amd_external_product_batch / _cmux_batch (reference src/trgsw.hpp:100-117) at the ring
+    sizes with NTT kernels, against the oracle's exact product: random operands, operands at the
+    ends of the centred range, and a batch that grows and shrinks (the per-device scratch is reused)."""
+    import tfhe_amd
+
+    p = tfhe_amd.Params(16, N, K, 8, L, 5, 2)
+    op = O.params_from(16, N, K, 8, L, 5, 2)
+    rs = np.random.RandomState(N + K + L)
+    R = (K + 1) * L
+    for batch in (3, 5, 1):
+        trgsw = rs.randint(0, 2**32, size=(batch, R, K + 1, N), dtype=np.uint64).astype(np.uint32)
+        d0 = rs.randint(0, 2**32, size=(batch, K + 1, N), dtype=np.uint64).astype(np.uint32)
+        d1 = rs.randint(0, 2**32, size=(batch, K + 1, N), dtype=np.uint64).astype(np.uint32)
+        # element 0: extreme magnitudes (key words +-2^31, digits of -128 everywhere)
+        trgsw[0] = np.where(rs.randint(0, 2, size=trgsw[0].shape) == 1, 0x80000000, 0x7FFFFFFF).astype(np.uint32)
+        d0[0] = 0x80808080 if L * 8 == 32 else (0x80800000 if L == 2 else 0x80808000)
+        got_ep = tfhe_amd.external_product(p, trgsw, d0)
+        got_cm = tfhe_amd.cmux(p, trgsw, d0, d1)
+        for i in range(batch):
+            assert np.array_equal(got_ep[i], O.external_product(trgsw[i], d0[i], op, O.NTT)), (batch, i)
+            assert np.array_equal(got_cm[i], O.cmux(trgsw[i], d0[i], d1[i], op, O.NTT)), (batch, i)

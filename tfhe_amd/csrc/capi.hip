@@ -591,30 +591,99 @@ int with_lane(tfhe_amd_ctx* ctx, void* stream, Body body) {
     return body(lease.lane, s);
 }
 
+// Per-device state of the stand-alone external product / cmux entry points, kept for the life of
+// the process and grown on demand, so that repeated calls neither allocate nor rebuild tables: the
+// staging buffers, the transformed TRGSW samples, the twiddle tables of every kernel family used.
+struct EpScratch {
+    std::mutex mu;  // one call at a time per device
+    hipStream_t stream = nullptr;
+    uint32_t* raw = nullptr;  // trgsw | x0 | x1 | out
+    size_t raw_words = 0;
+    d2* ntt = nullptr;        // transformed samples
+    size_t ntt_doubles = 0;
+    d2* tw[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] wave kernels (N = 512), [1..3] workgroup kernels, log2 N = 9..11
+    NttUniform u[4];
+};
+EpScratch g_ep[kMaxDevices];
+
+int ep_twiddles(EpScratch& sc, int family, int N) {
+    if (sc.tw[family]) return TFHE_AMD_OK;
+    const TwiddleSet tw = make_twiddles(N);
+    build_uniform(sc.u[family], tw);
+    const std::vector<double> blk = family == 0 ? build_tw_block_512(tw)
+                                    : family == 1 ? build_tw_table_wg<9>(tw)
+                                    : family == 2 ? build_tw_table_wg<10>(tw)
+                                                  : build_tw_table_wg<11>(tw);
+    HIP_TRY(hipMalloc(&sc.tw[family], blk.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(sc.tw[family], blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));
+    return TFHE_AMD_OK;
+}
+
 int external_product_common(const tfhe_amd_params* p, const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
                             uint32_t* out, size_t batch, int device, int mode) {
     if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
-    if (!generic_has_kernel(p->N, p->K, p->L))
+    const bool fast = external_product_512_has_kernel(p->N, p->K, p->L, p->bg_bit);
+    int tiles = 0, shift = 0, pack_shift = 0;
+    const bool wg = !fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit) &&
+                    wg_split(p->N, p->K, p->L, p->bg_bit, &tiles, &shift, &pack_shift);
+    if (!fast && !wg && !generic_has_kernel(p->N, p->K, p->L))
         return fail(TFHE_AMD_ERR_UNSUPPORTED, "ring too large for the generic kernel");
     if (batch && (!trgsw || !x0 || !out || (mode && !x1))) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
     if (batch == 0) return TFHE_AMD_OK;
+    if (batch > (size_t)1 << 24) return fail(TFHE_AMD_ERR_ARGUMENT, "batch too large");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
+    if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(TFHE_AMD_ERR_ARGUMENT, "no such device");
     DeviceGuard guard(device);
     if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
-    const size_t W = (size_t)(p->K + 1) * p->N, GW = W * (p->K + 1) * p->L;
-    DevBuf dg, d0, d1, dout;
-    HIP_TRY(dg.alloc(batch * GW * 4));
-    HIP_TRY(d0.alloc(batch * W * 4));
-    HIP_TRY(d1.alloc(batch * W * 4));
-    HIP_TRY(dout.alloc(batch * W * 4));
-    HIP_TRY(hipMemcpy(dg.p, trgsw, batch * GW * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d0.p, x0, batch * W * 4, hipMemcpyHostToDevice));
-    if (mode) HIP_TRY(hipMemcpy(d1.p, x1, batch * W * 4, hipMemcpyHostToDevice));
-    HIP_TRY(launch_external_product_generic(dg.as<uint32_t>(), d0.as<uint32_t>(), d1.as<uint32_t>(),
-                                            dout.as<uint32_t>(), batch, p->N, p->K, p->L, p->bg_bit, mode, nullptr));
-    HIP_TRY(hipMemcpy(out, dout.p, batch * W * 4, hipMemcpyDeviceToHost));
+    EpScratch& sc = g_ep[device];
+    std::lock_guard<std::mutex> lock(sc.mu);
+    if (!sc.stream) HIP_TRY(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
+    const size_t K1 = (size_t)p->K + 1, R = K1 * p->L;
+    const size_t W = K1 * p->N, GW = W * R, need = batch * (GW + 3 * W);
+    if (need > sc.raw_words) {
+        if (sc.raw) (void)hipFree(sc.raw);
+        sc.raw = nullptr;
+        sc.raw_words = 0;
+        HIP_TRY(hipMalloc(&sc.raw, need * sizeof(uint32_t)));
+        sc.raw_words = need;
+    }
+    uint32_t* d_g = sc.raw;
+    uint32_t* d_0 = d_g + batch * GW;
+    uint32_t* d_1 = d_0 + batch * W;
+    uint32_t* d_out = d_1 + batch * W;
+    HIP_TRY(hipMemcpyAsync(d_g, trgsw, batch * GW * 4, hipMemcpyHostToDevice, sc.stream));
+    HIP_TRY(hipMemcpyAsync(d_0, x0, batch * W * 4, hipMemcpyHostToDevice, sc.stream));
+    if (mode) HIP_TRY(hipMemcpyAsync(d_1, x1, batch * W * 4, hipMemcpyHostToDevice, sc.stream));
+    if (fast || wg) {
+        // the samples go through the key transform of the blind rotation (a "bootstrapping key" of
+        // `batch` rows), then one step body per element
+        const size_t ntt_doubles = fast ? batch * GW : batch * R * (size_t)tiles * p->N;
+        if (ntt_doubles > sc.ntt_doubles) {
+            if (sc.ntt) (void)hipFree(sc.ntt);
+            sc.ntt = nullptr;
+            sc.ntt_doubles = 0;
+            HIP_TRY(hipMalloc(&sc.ntt, ntt_doubles * sizeof(double)));
+            sc.ntt_doubles = ntt_doubles;
+        }
+        const int family = fast ? 0 : p->N == 512 ? 1 : p->N == 1024 ? 2 : 3;
+        int rc = ep_twiddles(sc, family, p->N);
+        if (rc) return rc;
+        if (fast) {
+            HIP_TRY(launch_bk_transform_512(sc.u[0], sc.tw[0], d_g, sc.ntt, (int)(batch * R * K1), sc.stream));
+            HIP_TRY(launch_external_product_512(sc.u[0], sc.tw[0], sc.ntt, d_0, d_1, d_out, batch, p->K, p->L, mode,
+                                                sc.stream));
+        } else {
+            HIP_TRY(launch_bk_transform_wg(sc.u[family], sc.tw[family], d_g, sc.ntt, batch * R, p->N, p->K, shift,
+                                           pack_shift, sc.stream));
+            HIP_TRY(launch_external_product_wg(sc.u[family], sc.tw[family], sc.ntt, d_0, d_1, d_out, batch, p->N, p->K,
+                                               p->L, shift, pack_shift, mode, sc.stream));
+        }
+    } else {
+        HIP_TRY(launch_external_product_generic(d_g, d_0, d_1, d_out, batch, p->N, p->K, p->L, p->bg_bit, mode, sc.stream));
+    }
+    HIP_TRY(hipMemcpyAsync(out, d_out, batch * W * 4, hipMemcpyDeviceToHost, sc.stream));
+    HIP_TRY(hipStreamSynchronize(sc.stream));
     return TFHE_AMD_OK;
 }
 

@@ -370,6 +370,90 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
 }
 
 // ------------------------------------------------------------------------------------------
+// TRGSW::external_product / TRGSW::cmux on explicit operands (reference src/trgsw.hpp:100-117),
+// default ring: one wave per batch element, the step body of the blind rotation without the
+// rotation.  key_ntt: the batch's TRGSW samples transformed by bk_transform_512_kernel (element e =
+// "row" e of a bootstrapping key).  mode 0: out = C (x) x0; mode 1: out = C (x) (x1 - x0) + x0.
+// ------------------------------------------------------------------------------------------
+template <int K, int L>
+__global__ void __launch_bounds__(256, 2)
+external_product_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2* __restrict__ key_ntt,
+                            const uint32_t* __restrict__ x0, const uint32_t* __restrict__ x1, uint32_t* __restrict__ out,
+                            int batch, int mode) {
+    constexpr int K1 = K + 1, R = K1 * L, BG = 8;
+    __shared__ d2 s_tw[kTwPairs];
+    __shared__ double s_tr[4][kTrPad];
+    for (int i = threadIdx.x; i < kTwPairs; i += 256) s_tw[i] = tw[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 4 + wave;
+    if (e >= batch) return;
+    double* tr = s_tr[wave];
+    const double p = u.p, pinv = u.pinv;
+    uint32_t offset = 1u << (32 - L * BG - 1), flip = 0u;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        offset += 1u << (32 - BG * (l + 1) + BG - 1);
+        flip |= 1u << (32 - BG * (l + 1) + BG - 1);
+    }
+    const uint32_t* a0 = x0 + (size_t)e * (K1 * kN);
+    const uint32_t* a1 = x1 + (size_t)e * (K1 * kN);
+    const d2* key_row = key_ntt + (size_t)e * (R * K1 * (kN / 2));
+
+    double acc[K1][8];
+#pragma unroll
+    for (int col = 0; col < K1; col++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[col][k] = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < K1; q++) {
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = q * kN + 64 * k + lane;
+            const uint32_t v = mode ? a1[j] - a0[j] : a0[j];
+            t[k] = (v + offset) ^ flip;
+        }
+#pragma unroll
+        for (int level = 0; level < L; level++) {
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = (double)(((int32_t)(t[k] << (BG * level))) >> (32 - BG));
+            ntt512_forward<true, false, true>(x, u, s_tw, tr, lane);  // |x| <= 3.2 p
+            const d2* key_poly = key_row + (size_t)(q * L + level) * K1 * (kN / 2);
+#pragma unroll
+            for (int col = 0; col < K1; col++) {
+                double yy[8], prod[8];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const d2 y = key_poly[col * (kN / 2) + kk * 64 + lane];
+                    yy[2 * kk] = y.x;
+                    yy[2 * kk + 1] = y.y;
+                }
+                mulmod_var_n<8>(prod, x, yy, p, pinv);  // <= 1.41 p each
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc[col][k] += prod[k];
+            }
+            // reduce after every third product: the running sum stays below 0.5 p + 3 * 1.41 p < 2^53
+            if ((q * L + level) % 3 == 2 && q * L + level != R - 1) {
+#pragma unroll
+                for (int col = 0; col < K1; col++) reduce_n<8>(acc[col], p, pinv);
+            }
+        }
+    }
+    uint32_t* o = out + (size_t)e * (K1 * kN);
+#pragma unroll
+    for (int col = 0; col < K1; col++) {
+        ntt512_inverse<true>(acc[col], u, s_tw, tr, lane);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = col * kN + 64 * k + lane;
+            o[j] = to_torus(acc[col][k], p, pinv) + (mode ? a0[j] : 0u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Blind rotation for small batches (latency form).  One WORKGROUP owns one gate; every
 // length-512 transform is split over two waves (ntt512_half.hpp), so a step is spread over
 // 2 (K+1) L = 12 waves, three per SIMD:
@@ -825,6 +909,21 @@ hipError_t launch_blind_rotate_512(const NttUniform& u, const d2* tw, const d2* 
         blind_rotate_512_kernel<2, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, tv, out, n_gates, n, extract);
     else
         blind_rotate_512_kernel<1, 2><<<blocks, 256, 0, stream>>>(u, tw, bk_ntt, c, tv, out, n_gates, n, extract);
+    return hipGetLastError();
+}
+
+bool external_product_512_has_kernel(int N, int K, int L, int bg) {
+    return N == 512 && (K == 1 || K == 2) && L == 2 && bg == 8;
+}
+
+hipError_t launch_external_product_512(const NttUniform& u, const d2* tw, const d2* key_ntt, const uint32_t* x0,
+                                       const uint32_t* x1, uint32_t* out, size_t batch, int K, int L, int mode,
+                                       hipStream_t stream) {
+    if (batch == 0) return hipSuccess;
+    if (!external_product_512_has_kernel(512, K, L, 8)) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((batch + 3) / 4);
+    if (K == 2) external_product_512_kernel<2, 2><<<blocks, 256, 0, stream>>>(u, tw, key_ntt, x0, x1, out, (int)batch, mode);
+    else        external_product_512_kernel<1, 2><<<blocks, 256, 0, stream>>>(u, tw, key_ntt, x0, x1, out, (int)batch, mode);
     return hipGetLastError();
 }
 

@@ -41,6 +41,15 @@ hipError_t launch_keygen_bk(uint32_t* bk, const uint8_t* s_lv0, const uint8_t* s
                             int bg_bit, double alpha, const KeygenSeed& seed, hipStream_t stream);
 hipError_t launch_keygen_ks(uint32_t* ks, const uint8_t* s_lv0, const uint8_t* s_lv1, int n, int nlv1, int T, int bb,
                             double alpha, const KeygenSeed& seed, hipStream_t stream);
+// stand-alone external product / cmux on the NTT kernels (kernels.hip, wg_kernels.hip); key_ntt: the
+// batch's TRGSW samples transformed like a bootstrapping key of `batch` rows
+bool external_product_512_has_kernel(int N, int K, int L, int bg);
+hipError_t launch_external_product_512(const NttUniform& u, const d2* tw, const d2* key_ntt, const uint32_t* x0,
+                                       const uint32_t* x1, uint32_t* out, size_t batch, int K, int L, int mode,
+                                       hipStream_t stream);
+hipError_t launch_external_product_wg(const NttUniform& u, const d2* table, const d2* key_ntt, const uint32_t* x0,
+                                      const uint32_t* x1, uint32_t* out, size_t batch, int N, int K, int L, int shift,
+                                      int pack_shift, int mode, hipStream_t stream);
 // exact O(N^2) kernels for any parameter set (generic_kernels.hip)
 bool generic_has_kernel(int N, int K, int L);
 hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,

@@ -207,6 +207,92 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
     }
 }
 
+// TRGSW::external_product / TRGSW::cmux on explicit operands (reference src/trgsw.hpp:100-117) for the
+// parameter sets of this file: one workgroup per batch element, the step body of the blind rotation
+// without the rotation.  key_ntt: the batch's TRGSW samples transformed and split by
+// bk_transform_wg_kernel (element e = "row" e of a bootstrapping key).  mode 0: out = C (x) x0;
+// mode 1: out = C (x) (x1 - x0) + x0.
+template <int LOGN, int K, int L>
+__global__ void __launch_bounds__(WgNtt<LOGN>::T, 2)
+external_product_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d2* __restrict__ key_ntt,
+                           const uint32_t* __restrict__ x0, const uint32_t* __restrict__ x1, uint32_t* __restrict__ out,
+                           int shift, int pack_shift, int mode) {
+    using W = WgNtt<LOGN>;
+    constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L, BG = 8;
+    constexpr int PACKS = (K1 + 1) / 2, TILES = K1 + PACKS;
+    __shared__ double s_tr[W::BUF_DOUBLES];
+    const int t = threadIdx.x;
+    const size_t e = blockIdx.x;
+    const double p = u.p, pinv = u.pinv;
+    uint32_t offset = 1u << (32 - L * BG - 1), flip = 0u;
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        offset += 1u << (32 - BG * (l + 1) + BG - 1);
+        flip |= 1u << (32 - BG * (l + 1) + BG - 1);
+    }
+    const double unpack = 1.0 / (double)(1u << pack_shift), pack = (double)(1u << pack_shift);
+    const uint32_t* a0 = x0 + e * (size_t)(K1 * N);
+    const uint32_t* a1 = x1 + e * (size_t)(K1 * N);
+    const d2* key_row = key_ntt + e * (size_t)(R * TILES) * (N / 2);
+
+    int parity = 0;
+    double acc_ntt[TILES][8];
+#pragma unroll
+    for (int tile = 0; tile < TILES; tile++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc_ntt[tile][k] = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < K1; q++) {
+        uint32_t tw_[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int j = q * N + k * T + t;
+            const uint32_t v = mode ? a1[j] - a0[j] : a0[j];
+            tw_[k] = (v + offset) ^ flip;
+        }
+        double x[L][8];
+#pragma unroll
+        for (int level = 0; level < L; level++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[level][k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
+        W::template forward_many<true, L>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
+        const d2* key_poly = key_row + (size_t)(q * L) * TILES * (N / 2);
+#pragma unroll
+        for (int level = 0; level < L; level++) {
+#pragma unroll
+            for (int tile = 0; tile < TILES; tile++) {
+                double yy[8], prod[8];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const d2 y = key_poly[(size_t)(level * TILES + tile) * (N / 2) + kk * T + t];
+                    yy[2 * kk] = y.x;
+                    yy[2 * kk + 1] = y.y;
+                }
+                mulmod_var_n<8>(prod, x[level], yy, p, pinv);
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc_ntt[tile][k] += prod[k];
+            }
+            if ((q * L + level) % 3 == 2 && q * L + level != R - 1) {
+#pragma unroll
+                for (int tile = 0; tile < TILES; tile++) reduce_n<8>(acc_ntt[tile], p, pinv);
+            }
+        }
+    }
+    W::template inverse_many<TILES>(acc_ntt, u, table, s_tr, parity, t);
+    uint32_t* o = out + e * (size_t)(K1 * N);
+#pragma unroll
+    for (int col = 0; col < K1; col++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double v = reduce(acc_ntt[K1 + col / 2][k], p, pinv);
+            const double h1 = __builtin_rint(v * unpack);
+            const uint32_t hi = (uint32_t)(int32_t)((col & 1) ? h1 : __builtin_fma(-h1, pack, v));
+            const int j = col * N + k * T + t;
+            o[j] = to_torus(acc_ntt[col][k], p, pinv) + (hi << shift) + (mode ? a0[j] : 0u);
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 
 // parameter sets with an instantiation (8-bit gadget, L = 2 or 3): N = 2048 with K = 1, N = 1024 with
@@ -258,6 +344,26 @@ hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const ui
     else if (N == 512) WG_KEY(9);
     else return hipErrorInvalidValue;
 #undef WG_KEY
+    return hipGetLastError();
+}
+
+hipError_t launch_external_product_wg(const NttUniform& u, const d2* table, const d2* key_ntt, const uint32_t* x0,
+                                      const uint32_t* x1, uint32_t* out, size_t batch, int N, int K, int L, int shift,
+                                      int pack_shift, int mode, hipStream_t stream) {
+    if (batch == 0) return hipSuccess;
+    if (!wg_has_kernel(N, K, L, 8)) return hipErrorInvalidValue;
+    int want_tiles = 0, want_shift = 0, want_pack = 0;
+    if (!wg_split(N, K, L, 8, &want_tiles, &want_shift, &want_pack) || shift != want_shift || pack_shift != want_pack)
+        return hipErrorInvalidValue;
+#define WG_EP(LOGN, KK, LL)                                                                                          \
+    external_product_wg_kernel<LOGN, KK, LL><<<(unsigned)batch, WgNtt<LOGN>::T, 0, stream>>>(u, table, key_ntt, x0, x1, out, \
+                                                                                             shift, pack_shift, mode)
+    if (N == 2048) { if (L == 3) WG_EP(11, 1, 3); else WG_EP(11, 1, 2); }
+    else if (N == 1024 && K == 1) { if (L == 3) WG_EP(10, 1, 3); else WG_EP(10, 1, 2); }
+    else if (N == 1024) { if (L == 3) WG_EP(10, 2, 3); else WG_EP(10, 2, 2); }
+    else if (K == 1) WG_EP(9, 1, 3);
+    else WG_EP(9, 2, 3);
+#undef WG_EP
     return hipGetLastError();
 }
 
