@@ -188,8 +188,17 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
         flip |= 1u << (32 - BG * (l + 1) + BG - 1);
     }
 
+#ifdef TFHE_AMD_PHASE_CLOCKS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define PH_START() tprev = __builtin_amdgcn_s_memtime()
+#define PH_MARK(I) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[I] += tn_ - tprev; tprev = tn_; }
+#else
+#define PH_START()
+#define PH_MARK(I)
+#endif
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
+        PH_START();
         if ((i & 63) == 0) cvals = (i + lane < n) ? cg[1 + i + lane] : 0u;
         const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cvals, i & 63);
         const int abar = (int)((ci + (1u << 21)) >> 22);  // round(a_i * 2N), in [0, 2N]
@@ -221,6 +230,10 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
                 const uint32_t v = acc[q][TFHE_AMD_EXPERIMENT_ALIGNED_ACC ? 64 * k + lane : src[k]];
                 t[k] = ((((v ^ neg[k]) - neg[k]) - acc[q][64 * k + lane]) + offset) ^ flip;
             }
+#ifdef TFHE_AMD_PHASE_CLOCKS
+            asm volatile("" :: "v"(t[0]), "v"(t[7]));
+#endif
+            PH_MARK(0)
 #if TFHE_AMD_PAIR_THROUGHPUT
             {
                 static_assert(L == 2 && (K1 == 2 || K1 == 3), "the two levels of a digit polynomial run as one interleaved pair");
@@ -269,7 +282,9 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
                         for (int kk = 0; kk < 4; kk++)
                             y[col][kk] = bk_poly[(K1 + col) * (kN / 2) + kk * 64 + lane];
                 });
+                PH_MARK(1)
                 mac(x1);
+                PH_MARK(2)
             }
 #else
 #pragma unroll
@@ -322,6 +337,7 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
         // |out| <= 4.74 p
 #if TFHE_AMD_PAIR_THROUGHPUT
         ntt512_inverse2(out[0], out[1], u, s_tw, tr, tr2, lane);
+        PH_MARK(3)
         auto update = [&](int col) {
 #pragma unroll
             for (int k = 0; k < 8; k++) acc[col][64 * k + lane] += to_torus(out[col][k], p, pinv);
@@ -344,7 +360,12 @@ blind_rotate_512_kernel(const NttUniform u, const d2* __restrict__ tw, const d2*
         }
 #endif
         wave_lds_fence();
+        PH_MARK(4)
     }
+#ifdef TFHE_AMD_PHASE_CLOCKS
+    if (gate == 5 && lane == 0)
+        printf("phase ticks gate 5: prep %llu fwd2+mac0 %llu mac1 %llu inv2 %llu inv3+update %llu\n", ph[0], ph[1], ph[2], ph[3], ph[4]);
+#endif
 
     if (!extract) {  // raw accumulator [K1][N]
         uint32_t* o = out + (size_t)gate * (K1 * kN);

@@ -267,6 +267,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 __device__ __forceinline__ void transpose_a_to_b(double (&x)[8], double* tr, int lane) {
+#ifdef TFHE_AMD_EXPERIMENT_NO_TRANSPOSE
+    return;  // timing experiment (wrong results): what the exchanges cost
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) tr[pad_pos(64 * k + lane)] = x[k];
     wave_lds_fence();
@@ -276,6 +279,9 @@ __device__ __forceinline__ void transpose_a_to_b(double (&x)[8], double* tr, int
     wave_lds_fence();
 }
 __device__ __forceinline__ void transpose_b_to_c(double (&x)[8], double* tr, int lane) {
+#ifdef TFHE_AMD_EXPERIMENT_NO_TRANSPOSE
+    return;  // timing experiment (wrong results): what the exchanges cost
+#endif
     const int base = 72 * (lane >> 3) + (lane & 7);
 #pragma unroll
     for (int k = 0; k < 8; k++) tr[base + 9 * k] = x[k];
@@ -285,6 +291,9 @@ __device__ __forceinline__ void transpose_b_to_c(double (&x)[8], double* tr, int
     wave_lds_fence();
 }
 __device__ __forceinline__ void transpose_c_to_b(double (&x)[8], double* tr, int lane) {
+#ifdef TFHE_AMD_EXPERIMENT_NO_TRANSPOSE
+    return;  // timing experiment (wrong results): what the exchanges cost
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) tr[9 * lane + k] = x[k];
     wave_lds_fence();
@@ -294,6 +303,9 @@ __device__ __forceinline__ void transpose_c_to_b(double (&x)[8], double* tr, int
     wave_lds_fence();
 }
 __device__ __forceinline__ void transpose_b_to_a(double (&x)[8], double* tr, int lane) {
+#ifdef TFHE_AMD_EXPERIMENT_NO_TRANSPOSE
+    return;  // timing experiment (wrong results): what the exchanges cost
+#endif
     const int base = 72 * (lane >> 3) + (lane & 7);
 #pragma unroll
     for (int k = 0; k < 8; k++) tr[base + 9 * k] = x[k];
