@@ -171,7 +171,7 @@ def test_n2048_ntt_path_vs_generic_and_oracle():
 
 
 @pytest.mark.parametrize("N,K,L", [(512, 1, 2), (512, 1, 3), (512, 2, 3), (1024, 1, 2), (1024, 1, 3), (1024, 2, 2),
-                                   (1024, 2, 3), (2048, 1, 2)])
+                                   (1024, 2, 3), (2048, 1, 2), (2048, 2, 2), (2048, 2, 3)])
 def test_workgroup_ntt_sets_vs_generic_and_oracle(N, K, L):
     """The other parameter sets with workgroup NTT kernels (one wave per gate at N = 512, two at
     N = 1024; split key except for (512, 1, 2)) vs the O(N^2) wrap-around kernels vs the oracle,
@@ -249,7 +249,8 @@ def test_config5_n2048_nand_vs_oracle():
     assert np.array_equal(O.decrypt_bits(got, s0, op), 1 - (bits_a & bits_b))
 
 
-@pytest.mark.parametrize("N,K,L", [(512, 2, 2), (512, 1, 2), (512, 2, 3), (1024, 1, 2), (1024, 2, 2), (2048, 1, 3)])
+@pytest.mark.parametrize("N,K,L", [(512, 2, 2), (512, 1, 2), (512, 2, 3), (1024, 1, 2), (1024, 2, 2), (2048, 1, 3),
+                                   (2048, 2, 2)])
 def test_stand_alone_external_product_and_cmux_on_ntt_kernels(N, K, L):
     """tfhe_amd_external_product_batch / _cmux_batch (reference src/trgsw.hpp:100-117) at the ring
     sizes with NTT kernels, against the oracle's exact product: random operands, operands at the

@@ -295,11 +295,11 @@ external_product_wg_kernel(const NttUniform u, const d2* __restrict__ table, con
 
 // ---- host side ---------------------------------------------------------------------------------
 
-// parameter sets with an instantiation (8-bit gadget, L = 2 or 3): N = 2048 with K = 1, N = 1024 with
+// parameter sets with an instantiation (8-bit gadget, L = 2 or 3): N = 2048 and N = 1024 with
 // K = 1 or 2, and N = 512 with L = 3 (the N = 512 sets with L = 2 have wave-per-gate kernels)
 bool wg_has_kernel(int N, int K, int L, int bg) {
     if (bg != 8 || (L != 2 && L != 3)) return false;
-    if (N == 2048) return K == 1;
+    if (N == 2048) return K == 1 || K == 2;
     if (N == 1024) return K == 1 || K == 2;
     if (N == 512) return L == 3;  // L = 2: wave-per-gate kernels (kernels.hip)
     return false;
@@ -310,7 +310,8 @@ int wg_table_pairs(int N) {
 }
 
 // Split of the key for a parameter set (see the top of this file): `shift` = bits of the signed
-// remainder lo, chosen so that a column's lo sum (K+1) L N 2^(bg-1) 2^(shift-1) stays below p/4;
+// remainder lo, the largest for which a column's lo sum (K+1) L N 2^(bg-1) 2^(shift-1) stays below p/2
+// (worst case, so no further margin is needed);
 // `pack_shift` = position of the odd column's hi sum inside a packed accumulator, the smallest with
 // 2^(pack_shift-1) above one hi sum H = (K+1) L N 2^(bg-1) 2^(32-shift-1) (so that rounding separates
 // the two) -- the packed sum H (1 + 2^pack_shift) must stay below p/2 as well.  Returns false if no
@@ -319,7 +320,7 @@ bool wg_split(int N, int K, int L, int bg, int* tiles, int* shift, int* pack_shi
     const double pp = 1711528530149377.0;
     const double terms = (double)(K + 1) * L * N * (double)(1u << (bg - 1));
     for (int s = 30; s >= 16; s--) {
-        if (terms * (double)(1u << (s - 1)) >= 0.25 * pp) continue;
+        if (terms * (double)(1u << (s - 1)) >= 0.49 * pp) continue;
         const double H = terms * (double)(1u << (32 - s - 1));
         int ps = 1;
         while ((double)(1u << (ps - 1)) <= H) ps++;
@@ -358,7 +359,8 @@ hipError_t launch_external_product_wg(const NttUniform& u, const d2* table, cons
 #define WG_EP(LOGN, KK, LL)                                                                                          \
     external_product_wg_kernel<LOGN, KK, LL><<<(unsigned)batch, WgNtt<LOGN>::T, 0, stream>>>(u, table, key_ntt, x0, x1, out, \
                                                                                              shift, pack_shift, mode)
-    if (N == 2048) { if (L == 3) WG_EP(11, 1, 3); else WG_EP(11, 1, 2); }
+    if (N == 2048 && K == 1) { if (L == 3) WG_EP(11, 1, 3); else WG_EP(11, 1, 2); }
+    else if (N == 2048) { if (L == 3) WG_EP(11, 2, 3); else WG_EP(11, 2, 2); }
     else if (N == 1024 && K == 1) { if (L == 3) WG_EP(10, 1, 3); else WG_EP(10, 1, 2); }
     else if (N == 1024) { if (L == 3) WG_EP(10, 2, 3); else WG_EP(10, 2, 2); }
     else if (K == 1) WG_EP(9, 1, 3);
@@ -379,7 +381,8 @@ hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2
 #define WG_GO(LOGN, KK, LL)                                                                                       \
     blind_rotate_wg_kernel<LOGN, KK, LL><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, out, n, \
                                                                                            shift, pack_shift, extract)
-    if (N == 2048) { if (L == 3) WG_GO(11, 1, 3); else WG_GO(11, 1, 2); }
+    if (N == 2048 && K == 1) { if (L == 3) WG_GO(11, 1, 3); else WG_GO(11, 1, 2); }
+    else if (N == 2048) { if (L == 3) WG_GO(11, 2, 3); else WG_GO(11, 2, 2); }
     else if (N == 1024 && K == 1) { if (L == 3) WG_GO(10, 1, 3); else WG_GO(10, 1, 2); }
     else if (N == 1024) { if (L == 3) WG_GO(10, 2, 3); else WG_GO(10, 2, 2); }
     else if (K == 1) WG_GO(9, 1, 3);
