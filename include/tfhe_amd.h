@@ -253,8 +253,8 @@ int tfhe_amd_multi_ctx_synchronize(tfhe_amd_multi_ctx* m);
 /* Which blind-rotation kernels a context uses:
  *   "ntt512"         N = 512 with L = 2 (the default set, and K = 1): wave-per-gate and
  *                    workgroup-per-gate NTT kernels
- *   "ntt-workgroup"  N = 2048 and N = 1024 with K = 1 or 2, N = 512 with L = 3 (L = 2 or 3,
- *                    8-bit gadget)
+ *   "ntt-workgroup"  N = 2048, N = 1024 and N = 512 with K = 1 or 2: 8-bit gadget with L = 2 or 3
+ *                    (except N = 512, L = 2: "ntt512"), 16-bit gadget with L = 1
  *   "generic"        exact O(N^2) kernels, any parameter set
  *   "reference-fft-wave" / "reference-fft-workgroup"   verification mode
  *   "none"           the context holds no bootstrapping key

@@ -273,3 +273,40 @@ def test_stand_alone_external_product_and_cmux_on_ntt_kernels(N, K, L):
         for i in range(batch):
             assert np.array_equal(got_ep[i], O.external_product(trgsw[i], d0[i], op, O.NTT)), (batch, i)
             assert np.array_equal(got_cm[i], O.cmux(trgsw[i], d0[i], d1[i], op, O.NTT)), (batch, i)
+
+
+@pytest.mark.parametrize("N,K", [(512, 1), (512, 2), (1024, 1), (1024, 2), (2048, 1), (2048, 2)])
+def test_sixteen_bit_gadget_on_workgroup_ntt_kernels(N, K):
+    """BG_BIT = 16 (L = 1), the reference's other gadget base below 32 (reference src/types.hpp:11-19,
+    src/trgsw.hpp:21): blind rotation and stand-alone external product / cmux on the workgroup NTT
+    kernels (every column with its own hi accumulator) against the O(N^2) kernels and the oracle,
+    including key words and digits at the ends of their ranges."""
+    import tfhe_amd
+
+    n = 4
+    p = tfhe_amd.Params(n, N, K, 16, 1, 5, 2)
+    op = O.params_from(n, N, K, 16, 1, 5, 2)
+    rs = np.random.RandomState(16 + N + K)
+    keys = [rs.randint(0, 2**32, size=p.bk_shape(), dtype=np.uint64).astype(np.uint32),
+            np.full(p.bk_shape(), 0x80000000, dtype=np.uint32),
+            np.full(p.bk_shape(), 0x7FFFFFFF, dtype=np.uint32)]
+    c = rs.randint(0, 2**32, size=(5, n + 1), dtype=np.uint64).astype(np.uint32)
+    tv = rs.randint(0, 2**32, size=(K + 1, N), dtype=np.uint64).astype(np.uint32)
+    tv[0, :] = 0x80000000   # digits of -32768 after the first rotation's difference
+    for bk in keys:
+        with tfhe_amd.Context(p, bk, None) as fast, tfhe_amd.Context(p, bk, None, generic_kernels=True) as gen:
+            assert fast.kernel_family() == "ntt-workgroup" and gen.kernel_family() == "generic"
+            for t in (None, tv):
+                got = fast.blind_rotate(c, t)
+                assert np.array_equal(got, gen.blind_rotate(c, t))
+                assert np.array_equal(got[0], O.blind_rotate(c[0], bk, op, O.NTT, tv=t))
+    R = K + 1
+    trgsw = rs.randint(0, 2**32, size=(3, R, K + 1, N), dtype=np.uint64).astype(np.uint32)
+    d0 = rs.randint(0, 2**32, size=(3, K + 1, N), dtype=np.uint64).astype(np.uint32)
+    d1 = rs.randint(0, 2**32, size=(3, K + 1, N), dtype=np.uint64).astype(np.uint32)
+    trgsw[0] = 0x80000000
+    d0[0] = 0x80000000
+    got_ep, got_cm = tfhe_amd.external_product(p, trgsw, d0), tfhe_amd.cmux(p, trgsw, d0, d1)
+    for i in range(3):
+        assert np.array_equal(got_ep[i], O.external_product(trgsw[i], d0[i], op, O.NTT))
+        assert np.array_equal(got_cm[i], O.cmux(trgsw[i], d0[i], d1[i], op, O.NTT))

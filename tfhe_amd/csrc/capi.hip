@@ -121,7 +121,7 @@ struct tfhe_amd_ctx {
     bool replica = false;          // products through a replay of the reference's FFT (verification)
     bool replica_generic = false;  // ... with the one-workgroup-per-gate kernel even at the default set
     d2* d_spec = nullptr;          // replica: key spectra
-    int tiles = 0, shift = 0, pack_shift = 0;  // key split of the wg path (wg_kernels.hip)
+    int tiles = 0, shift = 0, pack_shift = 0, pack = 0;  // key split of the wg path (wg_kernels.hip)
     NttUniform u{};
     d2* d_tw = nullptr;
     d2* d_bk_ntt = nullptr;        // fast path
@@ -454,8 +454,8 @@ int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, u
         HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)n_gates, p.n, p.K, p.L,
                                         extract, ctx->form, s));
     else if (ctx->wg)
-        HIP_TRY(launch_blind_rotate_wg(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, n_gates, p.n, p.N, p.K, p.L,
-                                       ctx->shift, ctx->pack_shift, extract, s));
+        HIP_TRY(launch_blind_rotate_wg(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit,
+                                       ctx->shift, ctx->pack_shift, ctx->pack, extract, s));
     else
         HIP_TRY(launch_blind_rotate_generic(ctx->d_bk_raw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit, extract,
                                             s));
@@ -623,9 +623,9 @@ int external_product_common(const tfhe_amd_params* p, const uint32_t* trgsw, con
                             uint32_t* out, size_t batch, int device, int mode) {
     if (!params_sane(p)) return fail(TFHE_AMD_ERR_ARGUMENT, "parameter set violates the reference's constraints");
     const bool fast = external_product_512_has_kernel(p->N, p->K, p->L, p->bg_bit);
-    int tiles = 0, shift = 0, pack_shift = 0;
+    int tiles = 0, shift = 0, pack_shift = 0, pack = 0;
     const bool wg = !fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit) &&
-                    wg_split(p->N, p->K, p->L, p->bg_bit, &tiles, &shift, &pack_shift);
+                    wg_split(p->N, p->K, p->L, p->bg_bit, &tiles, &shift, &pack_shift, &pack);
     if (!fast && !wg && !generic_has_kernel(p->N, p->K, p->L))
         return fail(TFHE_AMD_ERR_UNSUPPORTED, "ring too large for the generic kernel");
     if (batch && (!trgsw || !x0 || !out || (mode && !x1))) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
@@ -675,9 +675,9 @@ int external_product_common(const tfhe_amd_params* p, const uint32_t* trgsw, con
                                                 sc.stream));
         } else {
             HIP_TRY(launch_bk_transform_wg(sc.u[family], sc.tw[family], d_g, sc.ntt, batch * R, p->N, p->K, shift,
-                                           pack_shift, sc.stream));
+                                           pack_shift, pack, sc.stream));
             HIP_TRY(launch_external_product_wg(sc.u[family], sc.tw[family], sc.ntt, d_0, d_1, d_out, batch, p->N, p->K,
-                                               p->L, shift, pack_shift, mode, sc.stream));
+                                               p->L, p->bg_bit, shift, pack_shift, pack, mode, sc.stream));
         }
     } else {
         HIP_TRY(launch_external_product_generic(d_g, d_0, d_1, d_out, batch, p->N, p->K, p->L, p->bg_bit, mode, sc.stream));
@@ -739,7 +739,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     const bool special = !ctx->replica && !(flags & TFHE_AMD_CTX_GENERIC_KERNELS);
     ctx->fast = special && fast_supported(p);
     ctx->wg = special && !ctx->fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit) &&
-              wg_split(p->N, p->K, p->L, p->bg_bit, &ctx->tiles, &ctx->shift, &ctx->pack_shift);
+              wg_split(p->N, p->K, p->L, p->bg_bit, &ctx->tiles, &ctx->shift, &ctx->pack_shift, &ctx->pack);
     ctx->form = (flags & TFHE_AMD_CTX_LATENCY_FORM) ? 1 : (flags & TFHE_AMD_CTX_THROUGHPUT_FORM) ? 2 : 0;
     auto bail = [&](hipError_t e, const char* what) {
         tfhe_amd_ctx_destroy(ctx);
@@ -800,7 +800,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
                 src = up_bk.as<uint32_t>();
             }
             CTX_TRY(launch_bk_transform_wg(ctx->u, ctx->d_tw, src, ctx->d_bk_ntt, bk_words / p->N / (p->K + 1), p->N, p->K,
-                                           ctx->shift, ctx->pack_shift, ctx->stream));
+                                           ctx->shift, ctx->pack_shift, ctx->pack, ctx->stream));
         } else {
             CTX_TRY(hipMalloc(&ctx->d_bk_raw, bk_words * sizeof(uint32_t)));
             CTX_TRY(hipMemcpyAsync(ctx->d_bk_raw, bk, bk_words * sizeof(uint32_t),

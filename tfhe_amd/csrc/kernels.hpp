@@ -48,8 +48,8 @@ hipError_t launch_external_product_512(const NttUniform& u, const d2* tw, const 
                                        const uint32_t* x1, uint32_t* out, size_t batch, int K, int L, int mode,
                                        hipStream_t stream);
 hipError_t launch_external_product_wg(const NttUniform& u, const d2* table, const d2* key_ntt, const uint32_t* x0,
-                                      const uint32_t* x1, uint32_t* out, size_t batch, int N, int K, int L, int shift,
-                                      int pack_shift, int mode, hipStream_t stream);
+                                      const uint32_t* x1, uint32_t* out, size_t batch, int N, int K, int L, int bg,
+                                      int shift, int pack_shift, int pack, int mode, hipStream_t stream);
 // exact O(N^2) kernels for any parameter set (generic_kernels.hip)
 bool generic_has_kernel(int N, int K, int L);
 hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
@@ -70,11 +70,11 @@ hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks_packed, uin
 // workgroup-cooperative NTT path for N >= 1024 (wg_kernels.hip)
 bool wg_has_kernel(int N, int K, int L, int bg);
 int wg_table_pairs(int N);
-bool wg_split(int N, int K, int L, int bg, int* tiles, int* shift, int* pack_shift);
+bool wg_split(int N, int K, int L, int bg, int* tiles, int* shift, int* pack_shift, int* pack);
 hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_rows,
-                                  int N, int K, int shift, int pack_shift, hipStream_t stream);
+                                  int N, int K, int shift, int pack_shift, int pack, hipStream_t stream);
 hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2* bk_ntt, const uint32_t* c,
-                                  const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L,
-                                  int shift, int pack_shift, int extract, hipStream_t stream);
+                                  const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L, int bg,
+                                  int shift, int pack_shift, int pack, int extract, hipStream_t stream);
 
 }  // namespace tfhe_amd

@@ -137,18 +137,20 @@ struct WgNtt {
     }
 
     // M forward transforms group by group, so that every group's twiddle row is loaded once for
-    // all of them.  In: group-0 layout (position k*T + t), |x| <= 2^31 (SMALL: |x| <= 2^7).
+    // all of them.  In: group-0 layout (position k*T + t), |x| <= 2^31 (SMALL = 1: |x| <= 2^7, 8-bit
+    // gadget digits; SMALL = 2: |x| <= 2^15, 16-bit digits, where only the first stage's twiddle
+    // zeta^2 < 2^26 is small enough to need no reduction).
     // Out: last group's layout (position 8t + k, bit-reversed spectrum order), |x| <= 3.2 p.
     // Additive inputs are reduced at the first stage of groups >= 2 (SMALL) or >= 1; the bound
     // then stays below 4.2 p at every stage for LOGN <= 12.
-    template <bool SMALL, int M>
+    template <int SMALL, int M>
     __device__ static __forceinline__ void forward_many(double (&xs)[M][8], const NttUniform& u,
                                                         const d2* __restrict__ table, double* bufs, int& parity, int t) {
         const double p = u.p, pinv = u.pinv;
 #pragma unroll
         for (int m = 0; m < M; m++) {
             double (&x)[8] = xs[m];
-            if (SMALL) {
+            if (SMALL == 1) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const double a = x[k], b = x[k + 4];
@@ -163,6 +165,18 @@ struct WgNtt {
                 }
 #pragma unroll
                 for (int k = 4; k < 6; k++) bf_ct(x[k], x[k + 2], u.fw[3], u.fwp[3], p);
+            } else if (SMALL == 2) {
+                // |x * zeta^2| < 2^41.3: exact, far below p
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double a = x[k], b = x[k + 4];
+                    x[k] = __builtin_fma(b, u.zI, a);
+                    x[k + 4] = __builtin_fma(-b, u.zI, a);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int k = 0; k < 2; k++) bf_ct(x[4 * h + k], x[4 * h + k + 2], u.fw[2 + h], u.fwp[2 + h], p);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; k++) bf_ct(x[k], x[k + 4], u.fw[1], u.fwp[1], p);
@@ -184,7 +198,7 @@ struct WgNtt {
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 transpose(xs[m], bufs, parity, g - 1, g, t);
-                constexpr bool kAlways = !SMALL;
+                constexpr bool kAlways = SMALL == 0;
                 if (g == GROUPS - 1) {
                     ct_group<LAST, true>(xs[m], tw, p, pinv);
                 } else if (g >= 2 || kAlways) {
@@ -196,7 +210,7 @@ struct WgNtt {
         }
     }
 
-    template <bool SMALL>
+    template <int SMALL>
     __device__ static __forceinline__ void forward(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,
                                                    double* bufs, int& parity, int t) {
         double (&one)[1][8] = reinterpret_cast<double (&)[1][8]>(x);

@@ -30,11 +30,11 @@ __device__ __forceinline__ int32_t split_hi(int32_t v, int shift) { return (int3
 template <int LOGN>
 __global__ void __launch_bounds__(WgNtt<LOGN>::T)
 bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const uint32_t* __restrict__ bk,
-                       d2* __restrict__ bk_ntt, int K1, int shift, int pack_shift) {
+                       d2* __restrict__ bk_ntt, int K1, int shift, int pack_shift, int pack) {
     using W = WgNtt<LOGN>;
     __shared__ double s_tr[W::BUF_DOUBLES];
     const int t = threadIdx.x;
-    const int tiles = K1 + (K1 + 1) / 2;
+    const int tiles = K1 + (K1 + pack - 1) / pack;
     const size_t row = blockIdx.x / tiles;
     const int tile = blockIdx.x % tiles;
     const uint32_t* src = bk + row * K1 * W::N;
@@ -45,9 +45,10 @@ bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const u
         if (tile < K1) {
             x[k] = (double)split_lo((int32_t)src[(size_t)tile * W::N + j], shift);
         } else {
-            const int c0 = 2 * (tile - K1), c1 = c0 + 1;
+            const int c0 = pack * (tile - K1), c1 = c0 + 1;
             double v = (double)split_hi((int32_t)src[(size_t)c0 * W::N + j], shift);
-            if (c1 < K1) v += (double)split_hi((int32_t)src[(size_t)c1 * W::N + j], shift) * (double)(1 << pack_shift);
+            if (pack == 2 && c1 < K1)
+                v += (double)split_hi((int32_t)src[(size_t)c1 * W::N + j], shift) * (double)(1 << pack_shift);
             x[k] = v;  // |v| <= 2^(32 - shift) (1 + 2^pack_shift) < 2^31
         }
     }
@@ -67,14 +68,15 @@ bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const u
 // transpose barrier the other one computes.  Measured alternatives: one workgroup per CU with
 // the L digit transforms of a polynomial interleaved in each wave (more parallelism per wave,
 // fewer barriers) is 20 % slower, three workgroups per CU spill and are 35 % slower.
-template <int LOGN, int K, int L>
+template <int LOGN, int K, int L, int BG, int PACK>
 __global__ void __launch_bounds__(WgNtt<LOGN>::T, 2)
 blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d2* __restrict__ bk_ntt,
                        const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv, uint32_t* __restrict__ out,
                        int n, int shift, int pack_shift, int extract) {
     using W = WgNtt<LOGN>;
-    constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L, BG = 8;
-    constexpr int PACKS = (K1 + 1) / 2, TILES = K1 + PACKS;
+    constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L;
+    constexpr int PACKS = (K1 + PACK - 1) / PACK, TILES = K1 + PACKS, SMALL = BG == 8 ? 1 : 2;
+    static_assert((BG == 8 || BG == 16) && L * BG <= 31 && (PACK == 1 || PACK == 2), "gadget shape");
     __shared__ double s_tr[W::BUF_DOUBLES];
     __shared__ uint32_t s_acc[K1][N];
     const int t = threadIdx.x;
@@ -140,7 +142,7 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             for (int level = 0; level < L; level++)
 #pragma unroll
                 for (int k = 0; k < 8; k++) x[level][k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
-            W::template forward_many<true, L>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
+            W::template forward_many<SMALL, L>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
 #pragma unroll
             for (int level = 0; level < L; level++) {
 #pragma unroll
@@ -181,9 +183,13 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             uint32_t hi_sum[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const double v = reduce(acc_ntt[K1 + col / 2][k], p, pinv);
-                const double h1 = __builtin_rint(v * unpack);
-                hi_sum[k] = (uint32_t)(int32_t)((col & 1) ? h1 : __builtin_fma(-h1, pack, v));
+                const double v = reduce(acc_ntt[K1 + col / PACK][k], p, pinv);
+                if (PACK == 1) {
+                    hi_sum[k] = (uint32_t)__double2loint(v + 6755399441055744.0);  // low word of the exact integer
+                } else {
+                    const double h1 = __builtin_rint(v * unpack);
+                    hi_sum[k] = (uint32_t)(int32_t)((col & 1) ? h1 : __builtin_fma(-h1, pack, v));
+                }
             }
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -212,14 +218,15 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
 // without the rotation.  key_ntt: the batch's TRGSW samples transformed and split by
 // bk_transform_wg_kernel (element e = "row" e of a bootstrapping key).  mode 0: out = C (x) x0;
 // mode 1: out = C (x) (x1 - x0) + x0.
-template <int LOGN, int K, int L>
+template <int LOGN, int K, int L, int BG, int PACK>
 __global__ void __launch_bounds__(WgNtt<LOGN>::T, 2)
 external_product_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d2* __restrict__ key_ntt,
                            const uint32_t* __restrict__ x0, const uint32_t* __restrict__ x1, uint32_t* __restrict__ out,
                            int shift, int pack_shift, int mode) {
     using W = WgNtt<LOGN>;
-    constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L, BG = 8;
-    constexpr int PACKS = (K1 + 1) / 2, TILES = K1 + PACKS;
+    constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L;
+    constexpr int PACKS = (K1 + PACK - 1) / PACK, TILES = K1 + PACKS, SMALL = BG == 8 ? 1 : 2;
+    static_assert((BG == 8 || BG == 16) && L * BG <= 31 && (PACK == 1 || PACK == 2), "gadget shape");
     __shared__ double s_tr[W::BUF_DOUBLES];
     const int t = threadIdx.x;
     const size_t e = blockIdx.x;
@@ -255,7 +262,7 @@ external_product_wg_kernel(const NttUniform u, const d2* __restrict__ table, con
         for (int level = 0; level < L; level++)
 #pragma unroll
             for (int k = 0; k < 8; k++) x[level][k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
-        W::template forward_many<true, L>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
+        W::template forward_many<SMALL, L>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
         const d2* key_poly = key_row + (size_t)(q * L) * TILES * (N / 2);
 #pragma unroll
         for (int level = 0; level < L; level++) {
@@ -284,9 +291,14 @@ external_product_wg_kernel(const NttUniform u, const d2* __restrict__ table, con
     for (int col = 0; col < K1; col++) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const double v = reduce(acc_ntt[K1 + col / 2][k], p, pinv);
-            const double h1 = __builtin_rint(v * unpack);
-            const uint32_t hi = (uint32_t)(int32_t)((col & 1) ? h1 : __builtin_fma(-h1, pack, v));
+            const double v = reduce(acc_ntt[K1 + col / PACK][k], p, pinv);
+            uint32_t hi;
+            if (PACK == 1) {
+                hi = (uint32_t)__double2loint(v + 6755399441055744.0);  // low word of the exact integer
+            } else {
+                const double h1 = __builtin_rint(v * unpack);
+                hi = (uint32_t)(int32_t)((col & 1) ? h1 : __builtin_fma(-h1, pack, v));
+            }
             const int j = col * N + k * T + t;
             o[j] = to_torus(acc_ntt[col][k], p, pinv) + (hi << shift) + (mode ? a0[j] : 0u);
         }
@@ -295,14 +307,15 @@ external_product_wg_kernel(const NttUniform u, const d2* __restrict__ table, con
 
 // ---- host side ---------------------------------------------------------------------------------
 
-// parameter sets with an instantiation (8-bit gadget, L = 2 or 3): N = 2048 and N = 1024 with
-// K = 1 or 2, and N = 512 with L = 3 (the N = 512 sets with L = 2 have wave-per-gate kernels)
+// parameter sets with an instantiation: N = 2048 and N = 1024 with K = 1 or 2 and N = 512 with K = 1 or 2,
+// for the 8-bit gadget with L = 2 or 3 (except N = 512, L = 2, which has wave-per-gate kernels in
+// kernels.hip) and for the 16-bit gadget with L = 1
 bool wg_has_kernel(int N, int K, int L, int bg) {
+    if (K != 1 && K != 2) return false;
+    if (N != 512 && N != 1024 && N != 2048) return false;
+    if (bg == 16) return L == 1;
     if (bg != 8 || (L != 2 && L != 3)) return false;
-    if (N == 2048) return K == 1 || K == 2;
-    if (N == 1024) return K == 1 || K == 2;
-    if (N == 512) return L == 3;  // L = 2: wave-per-gate kernels (kernels.hip)
-    return false;
+    return !(N == 512 && L == 2);
 }
 
 int wg_table_pairs(int N) {
@@ -311,35 +324,39 @@ int wg_table_pairs(int N) {
 
 // Split of the key for a parameter set (see the top of this file): `shift` = bits of the signed
 // remainder lo, the largest for which a column's lo sum (K+1) L N 2^(bg-1) 2^(shift-1) stays below p/2
-// (worst case, so no further margin is needed);
-// `pack_shift` = position of the odd column's hi sum inside a packed accumulator, the smallest with
-// 2^(pack_shift-1) above one hi sum H = (K+1) L N 2^(bg-1) 2^(32-shift-1) (so that rounding separates
-// the two) -- the packed sum H (1 + 2^pack_shift) must stay below p/2 as well.  Returns false if no
-// such split exists.  `tiles` = polynomials per key row after the split.
-bool wg_split(int N, int K, int L, int bg, int* tiles, int* shift, int* pack_shift) {
+// (worst case, so no further margin is needed); one hi sum is then at most
+// H = (K+1) L N 2^(bg-1) 2^(32-shift-1).  `pack` = columns whose hi sums share an accumulator: 2
+// where H (1 + 2^pack_shift) stays below p/2 with `pack_shift` the smallest position that separates
+// the two by rounding (2^(pack_shift-1) > H), else 1 (the 16-bit gadget: every column its own hi
+// accumulator, H < p/2).  Returns false if no such split exists.  `tiles` = polynomials per key row
+// after the split.
+bool wg_split(int N, int K, int L, int bg, int* tiles, int* shift, int* pack_shift, int* pack) {
     const double pp = 1711528530149377.0;
     const double terms = (double)(K + 1) * L * N * (double)(1u << (bg - 1));
-    for (int s = 30; s >= 16; s--) {
+    for (int s = 30; s >= 8; s--) {
         if (terms * (double)(1u << (s - 1)) >= 0.49 * pp) continue;
         const double H = terms * (double)(1u << (32 - s - 1));
+        if (H >= 0.49 * pp) return false;
         int ps = 1;
-        while ((double)(1u << (ps - 1)) <= H) ps++;
-        if (ps > 30 || H * (1.0 + (double)(1u << ps)) >= 0.49 * pp) return false;
-        *tiles = (K + 1) + (K + 2) / 2;
+        while (ps <= 30 && (double)(1u << (ps - 1)) <= H) ps++;
+        const bool two = ps <= 30 && H * (1.0 + (double)(1u << ps)) < 0.49 * pp;
+        *pack = two ? 2 : 1;
+        *pack_shift = two ? ps : 0;
+        *tiles = (K + 1) + (K + *pack) / *pack;
         *shift = s;
-        *pack_shift = ps;
         return true;
     }
     return false;
 }
 
 hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const uint32_t* bk, d2* bk_ntt, size_t n_rows,
-                                  int N, int K, int shift, int pack_shift, hipStream_t stream) {
+                                  int N, int K, int shift, int pack_shift, int pack, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
-    const int tiles = (K + 1) + (K + 2) / 2;
+    if (pack != 1 && pack != 2) return hipErrorInvalidValue;
+    const int tiles = (K + 1) + (K + pack) / pack;
 #define WG_KEY(LOGN)                                                                                               \
     bk_transform_wg_kernel<LOGN><<<(unsigned)(n_rows * tiles), WgNtt<LOGN>::T, 0, stream>>>(u, table, bk, bk_ntt, K + 1, \
-                                                                                           shift, pack_shift)
+                                                                                           shift, pack_shift, pack)
     if (N == 2048) WG_KEY(11);
     else if (N == 1024) WG_KEY(10);
     else if (N == 512) WG_KEY(9);
@@ -348,45 +365,53 @@ hipError_t launch_bk_transform_wg(const NttUniform& u, const d2* table, const ui
     return hipGetLastError();
 }
 
+// instantiation table shared by the blind rotation and the stand-alone external product:
+// GO(LOGN, K, L, BG, PACK) for the parameter set (N, K, L, bg) whose split packs `pack` columns
+#define TFHE_AMD_WG_DISPATCH(GO)                                                                   \
+    if (bg == 8 && pack == 2) {                                                                    \
+        if (N == 2048 && K == 1) { if (L == 3) GO(11, 1, 3, 8, 2); else GO(11, 1, 2, 8, 2); }      \
+        else if (N == 2048) { if (L == 3) GO(11, 2, 3, 8, 2); else GO(11, 2, 2, 8, 2); }           \
+        else if (N == 1024 && K == 1) { if (L == 3) GO(10, 1, 3, 8, 2); else GO(10, 1, 2, 8, 2); } \
+        else if (N == 1024) { if (L == 3) GO(10, 2, 3, 8, 2); else GO(10, 2, 2, 8, 2); }           \
+        else if (K == 1) GO(9, 1, 3, 8, 2);                                                        \
+        else GO(9, 2, 3, 8, 2);                                                                    \
+    } else if (bg == 16 && pack == 1) {                                                            \
+        if (N == 2048) { if (K == 1) GO(11, 1, 1, 16, 1); else GO(11, 2, 1, 16, 1); }              \
+        else if (N == 1024) { if (K == 1) GO(10, 1, 1, 16, 1); else GO(10, 2, 1, 16, 1); }         \
+        else { if (K == 1) GO(9, 1, 1, 16, 1); else GO(9, 2, 1, 16, 1); }                          \
+    } else {                                                                                       \
+        return hipErrorInvalidValue;                                                               \
+    }
+
+// the key must have been split the way the parameter set requires (the kernels assume it)
+static bool wg_split_matches(int N, int K, int L, int bg, int shift, int pack_shift, int pack) {
+    int t = 0, s = 0, ps = 0, pk = 0;
+    return wg_has_kernel(N, K, L, bg) && wg_split(N, K, L, bg, &t, &s, &ps, &pk) && s == shift && ps == pack_shift &&
+           pk == pack;
+}
+
 hipError_t launch_external_product_wg(const NttUniform& u, const d2* table, const d2* key_ntt, const uint32_t* x0,
-                                      const uint32_t* x1, uint32_t* out, size_t batch, int N, int K, int L, int shift,
-                                      int pack_shift, int mode, hipStream_t stream) {
+                                      const uint32_t* x1, uint32_t* out, size_t batch, int N, int K, int L, int bg,
+                                      int shift, int pack_shift, int pack, int mode, hipStream_t stream) {
     if (batch == 0) return hipSuccess;
-    if (!wg_has_kernel(N, K, L, 8)) return hipErrorInvalidValue;
-    int want_tiles = 0, want_shift = 0, want_pack = 0;
-    if (!wg_split(N, K, L, 8, &want_tiles, &want_shift, &want_pack) || shift != want_shift || pack_shift != want_pack)
-        return hipErrorInvalidValue;
-#define WG_EP(LOGN, KK, LL)                                                                                          \
-    external_product_wg_kernel<LOGN, KK, LL><<<(unsigned)batch, WgNtt<LOGN>::T, 0, stream>>>(u, table, key_ntt, x0, x1, out, \
-                                                                                             shift, pack_shift, mode)
-    if (N == 2048 && K == 1) { if (L == 3) WG_EP(11, 1, 3); else WG_EP(11, 1, 2); }
-    else if (N == 2048) { if (L == 3) WG_EP(11, 2, 3); else WG_EP(11, 2, 2); }
-    else if (N == 1024 && K == 1) { if (L == 3) WG_EP(10, 1, 3); else WG_EP(10, 1, 2); }
-    else if (N == 1024) { if (L == 3) WG_EP(10, 2, 3); else WG_EP(10, 2, 2); }
-    else if (K == 1) WG_EP(9, 1, 3);
-    else WG_EP(9, 2, 3);
+    if (!wg_split_matches(N, K, L, bg, shift, pack_shift, pack)) return hipErrorInvalidValue;
+#define WG_EP(LOGN, KK, LL, BB, PP)                                                                                  \
+    external_product_wg_kernel<LOGN, KK, LL, BB, PP><<<(unsigned)batch, WgNtt<LOGN>::T, 0, stream>>>(                \
+        u, table, key_ntt, x0, x1, out, shift, pack_shift, mode)
+    TFHE_AMD_WG_DISPATCH(WG_EP)
 #undef WG_EP
     return hipGetLastError();
 }
 
 hipError_t launch_blind_rotate_wg(const NttUniform& u, const d2* table, const d2* bk_ntt, const uint32_t* c,
-                                  const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L,
-                                  int shift, int pack_shift, int extract, hipStream_t stream) {
+                                  const uint32_t* tv, uint32_t* out, size_t n_gates, int n, int N, int K, int L, int bg,
+                                  int shift, int pack_shift, int pack, int extract, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
-    if (!wg_has_kernel(N, K, L, 8)) return hipErrorInvalidValue;
-    // the key must have been split the way this parameter set requires (the kernels assume it)
-    int want_tiles = 0, want_shift = 0, want_pack = 0;
-    if (!wg_split(N, K, L, 8, &want_tiles, &want_shift, &want_pack) || shift != want_shift || pack_shift != want_pack)
-        return hipErrorInvalidValue;
-#define WG_GO(LOGN, KK, LL)                                                                                       \
-    blind_rotate_wg_kernel<LOGN, KK, LL><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(u, table, bk_ntt, c, tv, out, n, \
-                                                                                           shift, pack_shift, extract)
-    if (N == 2048 && K == 1) { if (L == 3) WG_GO(11, 1, 3); else WG_GO(11, 1, 2); }
-    else if (N == 2048) { if (L == 3) WG_GO(11, 2, 3); else WG_GO(11, 2, 2); }
-    else if (N == 1024 && K == 1) { if (L == 3) WG_GO(10, 1, 3); else WG_GO(10, 1, 2); }
-    else if (N == 1024) { if (L == 3) WG_GO(10, 2, 3); else WG_GO(10, 2, 2); }
-    else if (K == 1) WG_GO(9, 1, 3);
-    else WG_GO(9, 2, 3);
+    if (!wg_split_matches(N, K, L, bg, shift, pack_shift, pack)) return hipErrorInvalidValue;
+#define WG_GO(LOGN, KK, LL, BB, PP)                                                                                  \
+    blind_rotate_wg_kernel<LOGN, KK, LL, BB, PP><<<(unsigned)n_gates, WgNtt<LOGN>::T, 0, stream>>>(                  \
+        u, table, bk_ntt, c, tv, out, n, shift, pack_shift, extract)
+    TFHE_AMD_WG_DISPATCH(WG_GO)
 #undef WG_GO
     return hipGetLastError();
 }
