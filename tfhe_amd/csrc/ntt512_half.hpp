@@ -101,26 +101,63 @@ __device__ __forceinline__ void half_transpose_1_2(double (&x)[4]) {
     swap_rows(x[2], x[3]);
 }
 
+// The two butterflies of a stage are independent: they are issued phase by phase (ntt512.hpp) so
+// that a wave does not run them as two serial chains -- the latency form has one or two waves per
+// SIMD in its inverse phase and is bound by the dependent-issue latency there.
+#ifndef TFHE_AMD_HALF_PIN
+#define TFHE_AMD_HALF_PIN 1
+#endif
+__device__ __forceinline__ void bf_ct2(double& a0, double& b0, double w0, double wp0, double& a1, double& b1, double w1,
+                                       double wp1, double p) {
+    if (!TFHE_AMD_HALF_PIN) {
+        bf_ct(a0, b0, w0, wp0, p);
+        bf_ct(a1, b1, w1, wp1, p);
+        return;
+    }
+    const double b[2] = {b0, b1}, w[2] = {w0, w1}, wp[2] = {wp0, wp1};
+    double t[2];
+    mulmod_tw_n<2>(t, b, w, wp, p);
+    b0 = a0 - t[0];
+    b1 = a1 - t[1];
+    a0 = a0 + t[0];
+    a1 = a1 + t[1];
+    pin();
+}
+__device__ __forceinline__ void bf_gs2(double& a0, double& b0, double w0, double wp0, double& a1, double& b1, double w1,
+                                       double wp1, double p) {
+    if (!TFHE_AMD_HALF_PIN) {
+        bf_gs(a0, b0, w0, wp0, p);
+        bf_gs(a1, b1, w1, wp1, p);
+        return;
+    }
+    const double d[2] = {a0 - b0, a1 - b1}, w[2] = {w0, w1}, wp[2] = {wp0, wp1};
+    a0 = a0 + b0;
+    a1 = a1 + b1;
+    pin();
+    double t[2];
+    mulmod_tw_n<2>(t, d, w, wp, p);
+    b0 = t[0];
+    b1 = t[1];
+}
+
 // two Cooley-Tukey stages on 4 registers: pairs (0,2), (1,3), then (0,1), (2,3)
 template <bool REDUCE_A>
 __device__ __forceinline__ void ct4(double (&x)[4], const Tw3& t, double p, double pinv) {
     if (REDUCE_A) {
-        x[0] = reduce(x[0], p, pinv);
-        x[1] = reduce(x[1], p, pinv);
+        double a[2] = {x[0], x[1]};
+        reduce_n<2>(a, p, pinv);
+        x[0] = a[0];
+        x[1] = a[1];
     }
-    bf_ct(x[0], x[2], t.w[0], t.wp[0], p);
-    bf_ct(x[1], x[3], t.w[0], t.wp[0], p);
-    bf_ct(x[0], x[1], t.w[1], t.wp[1], p);
-    bf_ct(x[2], x[3], t.w[2], t.wp[2], p);
+    bf_ct2(x[0], x[2], t.w[0], t.wp[0], x[1], x[3], t.w[0], t.wp[0], p);
+    bf_ct2(x[0], x[1], t.w[1], t.wp[1], x[2], x[3], t.w[2], t.wp[2], p);
 }
 
 __device__ __forceinline__ void gs4_near(double (&x)[4], const Tw3& t, double p) {  // pairs (0,1), (2,3)
-    bf_gs(x[0], x[1], t.w[1], t.wp[1], p);
-    bf_gs(x[2], x[3], t.w[2], t.wp[2], p);
+    bf_gs2(x[0], x[1], t.w[1], t.wp[1], x[2], x[3], t.w[2], t.wp[2], p);
 }
 __device__ __forceinline__ void gs4_far(double (&x)[4], const Tw3& t, double p) {  // pairs (0,2), (1,3)
-    bf_gs(x[0], x[2], t.w[0], t.wp[0], p);
-    bf_gs(x[1], x[3], t.w[0], t.wp[0], p);
+    bf_gs2(x[0], x[2], t.w[0], t.wp[0], x[1], x[3], t.w[0], t.wp[0], p);
 }
 
 // Forward transform of 8-bit digits, half h.  d[k] = digit at position 64 k + lane of the full
@@ -145,8 +182,7 @@ __device__ __forceinline__ void half_forward_small(double (&x)[4], const double 
     }
     Tw3 t;
     load_tw3(t, s_tw + 3 * (half_row_offset(1) + half_row<1>(h, lane)));
-    bf_ct(x[0], x[1], t.w[1], t.wp[1], p);
-    bf_ct(x[2], x[3], t.w[2], t.wp[2], p);
+    bf_ct2(x[0], x[1], t.w[1], t.wp[1], x[2], x[3], t.w[2], t.wp[2], p);
 
     half_transpose_1_2(x);
     load_tw3(t, s_tw + 3 * (half_row_offset(2) + half_row<2>(h, lane)));
@@ -168,8 +204,7 @@ __device__ __forceinline__ void half_inverse(double (&x)[4], int h, const NttUni
                                              double* tr, int lane) {
     const double p = u.p, pinv = u.pinv;
     Tw3 t;
-#pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = reduce(x[k], p, pinv);
+    reduce_n<4>(x, p, pinv);
     load_tw3(t, s_tw_inv + 3 * (half_row_offset(4) + half_row<4>(h, lane)));
     gs4_near(x, t, p);
     gs4_far(x, t, p);
@@ -177,8 +212,7 @@ __device__ __forceinline__ void half_inverse(double (&x)[4], int h, const NttUni
     half_transpose<4, 3>(x, tr, lane);
     load_tw3(t, s_tw_inv + 3 * (half_row_offset(3) + half_row<3>(h, lane)));
     gs4_near(x, t, p);
-#pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = reduce(x[k], p, pinv);
+    reduce_n<4>(x, p, pinv);
     gs4_far(x, t, p);
 
     half_transpose<3, 2>(x, tr, lane);
@@ -187,12 +221,10 @@ __device__ __forceinline__ void half_inverse(double (&x)[4], int h, const NttUni
     gs4_far(x, t, p);
 
     half_transpose_1_2(x);
-#pragma unroll
-    for (int k = 0; k < 4; k++) x[k] = reduce(x[k], p, pinv);
+    reduce_n<4>(x, p, pinv);
     load_tw3(t, s_tw_inv + 3 * (half_row_offset(1) + half_row<1>(h, lane)));
     gs4_near(x, t, p);  // distance 64; the distance-128 stage follows
-    bf_gs(x[0], x[2], t.w[0], t.wp[0], p);
-    bf_gs(x[1], x[3], t.w[0], t.wp[0], p);
+    gs4_far(x, t, p);
 }
 
 }  // namespace tfhe_amd
