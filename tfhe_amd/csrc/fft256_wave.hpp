@@ -206,4 +206,34 @@ __device__ __forceinline__ uint32_t torus_from_double_fast(double d) {
     return t >= 4294967296.0 ? 0u : (uint32_t)t;
 }
 
+// Eight conversions at once, three FP64 instructions each.  f = d - floor(d) as above (round to
+// nearest), then f + 1.5 * 2^20 with the FP64 rounding mode set to "toward zero" for just those
+// additions: the sum lies in [1.5 * 2^20, 1.5 * 2^20 + 1], where a double's unit is 2^-32, so its low
+// mantissa word is floor(f * 2^32) mod 2^32 (f = 1 gives 2^32, i.e. 0, like the reference's
+// conversion through 64 bits).  The mode is bits 3:2 of the MODE register and is restored inside
+// the same instruction block.
+__device__ __forceinline__ void torus_from_double_8(uint32_t (&out)[8], const double (&d)[8]) {
+    double f[8], s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) f[i] = d[i] - __builtin_floor(d[i]);
+    const double c = 1572864.0;  // 1.5 * 2^20
+    asm volatile(
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3\n\t"
+        "s_nop 1\n\t"
+        "v_add_f64 %0, %8, %16\n\t"
+        "v_add_f64 %1, %9, %16\n\t"
+        "v_add_f64 %2, %10, %16\n\t"
+        "v_add_f64 %3, %11, %16\n\t"
+        "v_add_f64 %4, %12, %16\n\t"
+        "v_add_f64 %5, %13, %16\n\t"
+        "v_add_f64 %6, %14, %16\n\t"
+        "v_add_f64 %7, %15, %16\n\t"
+        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\t"
+        "s_nop 1"
+        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7])
+        : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]), "s"(c));
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = (uint32_t)__double2loint(s[i]);
+}
+
 }  // namespace tfhe_amd

@@ -340,6 +340,7 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                     }
                 }
                 fft256_wave2_rev(p0, p1, rows_inv, w23_inv, tr0, tr1, lane);
+                double vr[8], vi[8];  // untwisted real and imaginary parts: level 0 in [k], level 1 in [4 + k]
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const d2 u = s_untwist[64 * k + lane];
@@ -347,8 +348,18 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                     const double ad0 = p0.re[k] * u.y, bc0 = p0.im[k] * u.x;
                     const double ac1 = p1.re[k] * u.x, bd1 = p1.im[k] * u.y;
                     const double ad1 = p1.re[k] * u.y, bc1 = p1.im[k] * u.x;
-                    lo[col][k] += torus_from_double_fast(ac0 - bd0) + torus_from_double_fast(ac1 - bd1);
-                    hi[col][k] += torus_from_double_fast(ad0 + bc0) + torus_from_double_fast(ad1 + bc1);
+                    vr[k] = ac0 - bd0;
+                    vr[4 + k] = ac1 - bd1;
+                    vi[k] = ad0 + bc0;
+                    vi[4 + k] = ad1 + bc1;
+                }
+                uint32_t tr_[8], ti_[8];
+                torus_from_double_8(tr_, vr);
+                torus_from_double_8(ti_, vi);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    lo[col][k] += tr_[k] + tr_[4 + k];
+                    hi[col][k] += ti_[k] + ti_[4 + k];
                 }
             }
         }
