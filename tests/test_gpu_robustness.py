@@ -224,3 +224,11 @@ def test_host_pointer_calls_return_what_device_resident_calls_return(keysets):
         octx = O.Context(p, bk, ks)
         rows = np.array([0, 2047, 2048, 4095, 4096, n - 1])
         assert np.array_equal(ctx.nand(a, b)[rows], octx.nand_batch(a[rows], b[rows]))
+        # every row-wise host entry point returns what two smaller calls return
+        h = 2500
+        for call in (ctx.bootstrap, ctx.not_, ctx.gate_bootstrapping_tlwe_to_tlwe):
+            assert np.array_equal(call(a), np.concatenate([call(a[:h]), call(a[h:])])), call.__name__
+        lv1 = ctx.gate_bootstrapping_tlwe_to_tlwe(a)
+        assert np.array_equal(ctx.identity_key_switch(lv1),
+                              np.concatenate([ctx.identity_key_switch(lv1[:h]), ctx.identity_key_switch(lv1[h:])]))
+        assert np.array_equal(ctx.identity_key_switch(lv1), ctx.bootstrap(a))
