@@ -310,3 +310,47 @@ def test_sixteen_bit_gadget_on_workgroup_ntt_kernels(N, K):
     for i in range(3):
         assert np.array_equal(got_ep[i], O.external_product(trgsw[i], d0[i], op, O.NTT))
         assert np.array_equal(got_cm[i], O.cmux(trgsw[i], d0[i], d1[i], op, O.NTT))
+
+
+def _random_parameter_sets(count, seed):
+    """Parameter sets drawn from everything the reference's constraints allow (8- or 16-bit gadget with
+    L * bg_bit <= 31, T * base_bit <= 31, base_bit <= 3 for the table size, power-of-two ring)."""
+    rs = np.random.RandomState(seed)
+    sets = []
+    while len(sets) < count:
+        N = 1 << rs.randint(1, 11)          # 2 .. 1024
+        K = int(rs.randint(1, 5))           # 1 .. 4
+        bg = int(rs.choice([8, 16]))
+        L = 1 if bg == 16 else int(rs.randint(1, 4))
+        bb = int(rs.randint(1, 4))
+        T = int(rs.randint(1, min(31 // bb, 10) + 1))
+        n = int(rs.randint(1, 13))
+        if N * K > 2048 or (N * K * L * (K + 1)) > 16384:
+            continue                         # keeps the O(N^2) oracle and kernels to a second or two per set
+        sets.append((n, int(N), K, bg, L, T, bb))
+    return sets
+
+
+@pytest.mark.parametrize("shape", _random_parameter_sets(24, seed=2024))
+def test_random_parameter_sets_vs_oracle(shape):
+    """The whole gate (reference src/hom_nand.hpp:74-81) at parameter sets nobody picked by hand: the kernels
+    chosen by the library for each set (NTT where one exists, the exact O(N^2) ones elsewhere) against the
+    oracle's schoolbook multiplier, bit for bit, on random keys and ciphertexts."""
+    import tfhe_amd
+
+    n, N, K, bg, L, T, bb = shape
+    p = tfhe_amd.Params(*shape)
+    op = O.params_from(*shape)
+    rs = np.random.RandomState(n * 7919 + N + 31 * K + bg + L + T + bb)
+    bk = rs.randint(0, 2**32, size=p.bk_shape(), dtype=np.uint64).astype(np.uint32)
+    ks = rs.randint(0, 2**32, size=p.ks_shape(), dtype=np.uint64).astype(np.uint32)
+    a = rs.randint(0, 2**32, size=(5, n + 1), dtype=np.uint64).astype(np.uint32)
+    b = rs.randint(0, 2**32, size=(5, n + 1), dtype=np.uint64).astype(np.uint32)
+    a[0], b[0] = 0, 0xFFFFFFFF                       # extreme words
+    with tfhe_amd.Context(p, bk, ks) as ctx:
+        got = ctx.nand(a, b)
+        c = np.stack([O.nand_combine(x, y, op) for x, y in zip(a, b)])
+        acc = ctx.blind_rotate(c)
+    for i in range(a.shape[0]):
+        assert np.array_equal(acc[i], O.blind_rotate(c[i], bk, op, O.SCHOOLBOOK)), (shape, i)
+        assert np.array_equal(got[i], O.nand(a[i], b[i], bk, ks, op, O.SCHOOLBOOK)), (shape, i)
