@@ -40,6 +40,12 @@ template <> struct signed_int_of<32> { using type = int32_t; };
 template <int N, std::enable_if_t<is_valid_int_bits_v<N>>* = nullptr>
 using SignedInt = typename detail::signed_int_of<N>::type;
 
+namespace detail {
+// element type of a product of containers
+template <typename A, typename B>
+using product_t = decltype(std::declval<A>() * std::declval<B>());
+}  // namespace detail
+
 // ---- torus scalar (reference src/types.hpp:21-92) -------------------------------------------
 // An element of R/Z stored as raw / 2^32; all arithmetic wraps modulo 2^32.
 class TorusValue {
@@ -97,12 +103,20 @@ protected:
     Self& self() { return static_cast<Self&>(*this); }
     const Self& self() const { return static_cast<const Self&>(*this); }
 
+    static Value* fresh() { return new Value[N > 0 ? N : 1](); }
+
 public:
-    _VectorOrPolynomial() : _val(new Value[N > 0 ? N : 1]()) {}
-    _VectorOrPolynomial(const std::unique_ptr<Value[]>& src) : _val(new Value[N > 0 ? N : 1]()) {
-        for (int i = 0; i < N; i++) _val[i] = src[i];
-    }
+    _VectorOrPolynomial() : _val(fresh()) {}
+    _VectorOrPolynomial(const std::unique_ptr<Value[]>& src) : _val(fresh()) { std::copy_n(src.get(), N, _val.get()); }
     _VectorOrPolynomial(std::unique_ptr<Value[]>&& src) : _val(std::move(src)) {}
+    // the containers built on this block take their copy and move operations from here
+    _VectorOrPolynomial(const _VectorOrPolynomial& o) : _VectorOrPolynomial(o._val) {}
+    _VectorOrPolynomial(_VectorOrPolynomial&&) = default;
+    _VectorOrPolynomial& operator=(const _VectorOrPolynomial& o) {
+        if (this != &o) std::copy_n(o._val.get(), N, _val.get());
+        return *this;
+    }
+    _VectorOrPolynomial& operator=(_VectorOrPolynomial&&) = default;
 
     Value* begin() { return _val.get(); }
     const Value* begin() const { return _val.get(); }
@@ -168,28 +182,18 @@ class Polynomial : public _VectorOrPolynomial<Value, N, Polynomial<Value, N>> {
     friend Base;
 
 public:
-    Polynomial() : Base() {}
-    Polynomial(const Polynomial& o) : Base(o._val) {}
-    Polynomial(Polynomial&& o) : Base(std::move(o._val)) {}
-    Polynomial(const std::unique_ptr<Value[]>& v) : Base(v) {}
-    Polynomial(std::unique_ptr<Value[]>&& v) : Base(std::move(v)) {}
-
-    Polynomial& operator=(const Polynomial& o) {
-        if (this != &o) std::copy(o.begin(), o.end(), this->begin());
-        return *this;
-    }
-    Polynomial& operator=(Polynomial&& o) {
-        if (this != &o) this->_val = std::move(o._val);
-        return *this;
-    }
+    using Base::Base;  // default, from an owned block, from a copied block
+    Polynomial() = default;
+    Polynomial(const Polynomial&) = default;
+    Polynomial(Polynomial&&) = default;
+    Polynomial& operator=(const Polynomial&) = default;
+    Polynomial& operator=(Polynomial&&) = default;
 
     // Negacyclic product: r_k = sum_{i+j=k} a_i b_j - sum_{i+j=k+N} a_i b_j, accumulated in the
     // result type (wrap-around for integers and TorusValue).
     template <typename RHSValue>
-    Polynomial<decltype(std::declval<Value>() * std::declval<RHSValue>()), N> operator*(
-        const Polynomial<RHSValue, N>& rhs) const {
-        using Result = decltype(std::declval<Value>() * std::declval<RHSValue>());
-        Polynomial<Result, N> out;
+    Polynomial<detail::product_t<Value, RHSValue>, N> operator*(const Polynomial<RHSValue, N>& rhs) const {
+        Polynomial<detail::product_t<Value, RHSValue>, N> out;
         for (int i = 0; i < N; i++) {
             const Value& ai = (*this)[i];
             if (ai == Value{}) continue;
@@ -232,25 +236,16 @@ class Vector : public _VectorOrPolynomial<Value, N, Vector<Value, N>> {
     friend Matrix<Value, N, N>;
 
 public:
-    Vector() : Base() {}
-    Vector(const Vector& o) : Base(o._val) {}
-    Vector(Vector&& o) : Base(std::move(o._val)) {}
-    Vector(const std::unique_ptr<Value[]>& v) : Base(v) {}
-    Vector(std::unique_ptr<Value[]>&& v) : Base(std::move(v)) {}
-
-    Vector& operator=(const Vector& o) {
-        if (this != &o) std::copy(o.begin(), o.end(), this->begin());
-        return *this;
-    }
-    Vector& operator=(Vector&& o) {
-        if (this != &o) this->_val = std::move(o._val);
-        return *this;
-    }
+    using Base::Base;
+    Vector() = default;
+    Vector(const Vector&) = default;
+    Vector(Vector&&) = default;
+    Vector& operator=(const Vector&) = default;
+    Vector& operator=(Vector&&) = default;
 
     template <typename RHSValue>
-    decltype(std::declval<Value>() * std::declval<RHSValue>()) dot(const Vector<RHSValue, N>& rhs) const {
-        using Result = decltype(std::declval<Value>() * std::declval<RHSValue>());
-        Result acc{};
+    detail::product_t<Value, RHSValue> dot(const Vector<RHSValue, N>& rhs) const {
+        detail::product_t<Value, RHSValue> acc{};
         for (int i = 0; i < N; i++) acc += (*this)[i] * rhs[i];
         return acc;
     }
@@ -270,14 +265,12 @@ class Matrix {
     Vector<Vector<Value, N>, M> _val;
 
 public:
-    Matrix() : _val() {}
-    Matrix(const Matrix& o) : _val(o._val) {}
-    Matrix(Matrix&& o) : _val(std::move(o._val)) {}
-    Matrix& operator=(const Matrix& o) { _val = o._val; return *this; }
-    Matrix& operator=(Matrix&& o) {
-        if (this != &o) _val = std::move(o._val);
-        return *this;
-    }
+    // value semantics come from the rows
+    Matrix() = default;
+    Matrix(const Matrix&) = default;
+    Matrix(Matrix&&) = default;
+    Matrix& operator=(const Matrix&) = default;
+    Matrix& operator=(Matrix&&) = default;
 
     auto begin() { return _val.begin(); }
     auto begin() const { return _val.begin(); }
@@ -298,27 +291,25 @@ public:
     Matrix operator-(const Matrix& o) const { Matrix r(*this); r -= o; return r; }
 
     template <typename RHSValue, int O>
-    Matrix<decltype(std::declval<Value>() * std::declval<RHSValue>()), M, O> operator*(
-        const Matrix<RHSValue, N, O>& rhs) const {
-        Matrix<decltype(std::declval<Value>() * std::declval<RHSValue>()), M, O> out;
+    Matrix<detail::product_t<Value, RHSValue>, M, O> operator*(const Matrix<RHSValue, N, O>& rhs) const {
+        Matrix<detail::product_t<Value, RHSValue>, M, O> out;
         for (int i = 0; i < M; i++)
             for (int j = 0; j < N; j++)
                 for (int k = 0; k < O; k++) out[i][k] += (*this)[i][j] * rhs[j][k];
         return out;
     }
     template <typename RHSValue>
-    Vector<decltype(std::declval<Value>() * std::declval<RHSValue>()), M> operator*(
-        const Vector<RHSValue, N>& rhs) const {
-        Vector<decltype(std::declval<Value>() * std::declval<RHSValue>()), M> out;
+    Vector<detail::product_t<Value, RHSValue>, M> operator*(const Vector<RHSValue, N>& rhs) const {
+        Vector<detail::product_t<Value, RHSValue>, M> out;
         for (int i = 0; i < M; i++)
             for (int j = 0; j < N; j++) out[i] += (*this)[i][j] * rhs[j];
         return out;
     }
     // row vector times matrix: out[j] = sum_i lhs[i] * rhs[i][j]
     template <typename LHSValue>
-    friend Vector<decltype(std::declval<LHSValue>() * std::declval<Value>()), N> operator*(
-        const Vector<LHSValue, M>& lhs, const Matrix<Value, M, N>& rhs) {
-        Vector<decltype(std::declval<LHSValue>() * std::declval<Value>()), N> out;
+    friend Vector<detail::product_t<LHSValue, Value>, N> operator*(const Vector<LHSValue, M>& lhs,
+                                                                   const Matrix<Value, M, N>& rhs) {
+        Vector<detail::product_t<LHSValue, Value>, N> out;
         for (int i = 0; i < M; i++)
             for (int j = 0; j < N; j++) out[j] += lhs[i] * rhs[i][j];
         return out;
