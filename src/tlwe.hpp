@@ -22,6 +22,9 @@ public:
     constexpr static int N = TLWEParameter::N;
     constexpr static double ALPHA = TLWEParameter::ALPHA;
 
+    using Sample = Vector<TorusValue, N + 1>;  // [b, a_0 .. a_{N-1}]
+    using Key = Vector<bool, N>;
+
 private:
     Random random;
 
@@ -29,11 +32,11 @@ public:
     TLWE() : random{} {}
     explicit TLWE(uint64_t seed) : random{seed} {}
 
-    Vector<bool, N> generate_s() { return random.template bit_vector<N>(); }
+    Key generate_s() { return random.template bit_vector<N>(); }
 
     // b = <a, s> + m + e with a uniform and e ~ N(0, ALPHA^2) (reference src/tlwe.hpp:55-61)
-    Vector<TorusValue, N + 1> encrypt(const TorusValue& m, const Vector<bool, N>& s) {
-        Vector<TorusValue, N + 1> ct;
+    Sample encrypt(const TorusValue& m, const Key& s) {
+        Sample ct;
         TorusValue b = m + TorusValue{random.normal() * ALPHA};
         for (int i = 0; i < N; i++) {
             const TorusValue a = random.uniform_torus();
@@ -43,18 +46,18 @@ public:
         ct[0] = b;
         return ct;
     }
-    Vector<TorusValue, N + 1> encrypt_single_binary(bool m, const Vector<bool, N>& s) {
+    Sample encrypt_single_binary(bool m, const Key& s) {
         return encrypt(TorusValue(m), s);
     }
 
     // phase b - <a, s> (reference src/tlwe.hpp:67-71)
-    TorusValue decrypt(const Vector<TorusValue, N + 1>& ba, const Vector<bool, N>& s) {
+    TorusValue decrypt(const Sample& ba, const Key& s) {
         TorusValue phase = ba[0];
         for (int i = 0; i < N; i++)
             if (s[i]) phase -= ba[1 + i];
         return phase;
     }
-    bool decrypt_single_binary(const Vector<TorusValue, N + 1>& ba, const Vector<bool, N>& s) {
+    bool decrypt_single_binary(const Sample& ba, const Key& s) {
         return static_cast<bool>(decrypt(ba, s));
     }
 };

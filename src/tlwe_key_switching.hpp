@@ -20,7 +20,9 @@ public:
     constexpr static int N_LV1 = TLWELv1::N;
     constexpr static int T = TLWEKeySwitchingParameter::T;
     constexpr static int BASE_BIT = TLWEKeySwitchingParameter::BASE_BIT;
-    using Key = Vector<Vector<Vector<Vector<TorusValue, N_LV0 + 1>, (1 << BASE_BIT)>, T>, N_LV1>;
+    using SampleLv0 = Vector<TorusValue, N_LV0 + 1>;
+    using SampleLv1 = Vector<TorusValue, N_LV1 + 1>;
+    using Key = Vector<Vector<Vector<SampleLv0, (1 << BASE_BIT)>, T>, N_LV1>;  // [coefficient][level][digit]
 
 private:
     TLWELv0& tlwe_lv0;
@@ -43,7 +45,7 @@ public:
 
     // (b, 0..0) - sum over i, m of ks[i][m][digit_m(a_i)], on the GPU
     // (reference src/tlwe_key_switching.hpp:47-65)
-    Vector<TorusValue, N_LV0 + 1> identity_key_switch(const Vector<TorusValue, N_LV1 + 1>& ba_lv1, const Key& ks) {
+    SampleLv0 identity_key_switch(const SampleLv1& ba_lv1, const Key& ks) {
         tfhe_amd_params p;
         p.n = N_LV0;
         p.N = N_LV1 & -N_LV1;  // the key switch only sees N*K = N_LV1
