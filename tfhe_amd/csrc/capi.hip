@@ -13,6 +13,7 @@
 #include <new>
 #include <thread>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "../../include/tfhe_amd.h"
@@ -1207,7 +1208,13 @@ int on_all_devices(tfhe_amd_multi_ctx* m, Body body) {
     };
     std::vector<std::thread> workers;
     workers.reserve(P);
-    for (size_t g = 1; g < P; g++) workers.emplace_back(run, g);
+    for (size_t g = 1; g < P; g++) {
+        try {
+            workers.emplace_back(run, g);
+        } catch (const std::system_error&) {
+            run(g);  // no thread to spare: this device's share runs on the caller's thread
+        }
+    }
     run(0);
     for (std::thread& t : workers) t.join();
     for (size_t g = 0; g < P; g++)
