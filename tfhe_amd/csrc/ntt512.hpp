@@ -20,6 +20,8 @@
 // the matching Gentleman-Sande form.  The 1/N factor is folded into the bootstrapping key.
 #pragma once
 
+#include <utility>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -197,6 +199,95 @@ __device__ __forceinline__ void reduce_n(double (&x)[NB], double p, double pinv)
     pin();
 }
 
+// ---- lazy reductions of an inverse transform, planned at compile time -----------------------
+// Bounds in units of p.  A Gentleman-Sande butterfly maps (a, b) to (a + b, mulmod(a - b)); the
+// difference must stay below 2^53 = 5.26 p, and a product is at most (0.5 + 0.75 |d| / 5.26) p.  Only
+// the sum outputs grow, so after a group of stages few registers are large: the bound of register k
+// depends on k alone, and a register is reduced (to p/2) only where the plan says so:
+//   * before a stage, both operands of every pair whose bounds add up to more than kGsPairLimit;
+//   * after a group, before its transposition, every register above kGsCarryLimit.  After the
+//     transposition a lane holds eight values of one such class, so the next group starts from the
+//     largest bound that was left.
+// The transform's inputs are taken as the full 5.26 p, which makes the first stage reduce them all.
+// Groups are numbered like the stage groups of a transform: the inverse runs from group `groups - 1`
+// (`last` stages, 1 to 3) down to group 0 (three stages); stage s of a group pairs registers 2^s apart.
+constexpr double kGsPairLimit = 5.2, kGsCarryLimit = 1.3, kGsTwo53 = 5.26, kGsEps = 1e-6;
+struct GsPlan {
+    unsigned pre[4][3];  // [group][stage]: registers reduced before the stage (bit k)
+    unsigned carry[4];   // [group]: registers reduced after the group
+    double out;          // bound of the transform's outputs
+};
+constexpr GsPlan make_gs_plan(int groups, int last, bool classic = false) {
+    GsPlan pl{};
+    if (classic) {  // every group starts from eight reduced registers: outputs of a group <= 4 p
+        for (int g = 0; g < groups; g++) pl.pre[g][0] = 0xFFu;
+        pl.out = 4.0;
+        return pl;
+    }
+    double b[8] = {kGsTwo53, kGsTwo53, kGsTwo53, kGsTwo53, kGsTwo53, kGsTwo53, kGsTwo53, kGsTwo53};
+    for (int g = groups - 1; g >= 0; g--) {
+        const int st = g == groups - 1 ? last : 3;
+        for (int s = 0; s < st; s++) {
+            const int dist = 1 << s;
+            for (int i = 0; i < 4; i++) {
+                const int lo = (i / dist) * 2 * dist + (i % dist), hi = lo + dist;
+                if (b[lo] + b[hi] > kGsPairLimit) {
+                    pl.pre[g][s] |= (1u << lo) | (1u << hi);
+                    b[lo] = b[hi] = 0.5 + kGsEps;
+                }
+                const double d = b[lo] + b[hi];
+                b[lo] = d;
+                b[hi] = 0.5 + 0.75 * d / kGsTwo53 + kGsEps;
+            }
+        }
+        if (g > 0) {
+            double top = 0.5 + kGsEps;
+            for (int k = 0; k < 8; k++) {
+                if (b[k] > kGsCarryLimit) pl.carry[g] |= 1u << k;
+                else if (b[k] > top) top = b[k];
+            }
+            for (int k = 0; k < 8; k++) b[k] = top;
+        }
+    }
+    pl.out = 0.0;
+    for (int k = 0; k < 8; k++) pl.out = b[k] > pl.out ? b[k] : pl.out;
+    return pl;
+}
+
+constexpr int gs_popcount(unsigned m) { return m ? (int)(m & 1u) + gs_popcount(m >> 1) : 0; }
+constexpr int gs_nth_bit(unsigned m, int n) {  // index of the n-th set bit
+    int k = 0;
+    for (;; k++)
+        if ((m >> k) & 1u) {
+            if (n == 0) break;
+            n--;
+        }
+    return k;
+}
+
+// centred residues of the registers in MASK, phase-ordered like reduce_n
+template <unsigned MASK, int I>
+struct GsNthBit {
+    static constexpr int value = gs_nth_bit(MASK, I);
+};
+template <unsigned MASK, bool PIN, int... I>
+__device__ __forceinline__ void reduce_masked_impl(double (&x)[8], double p, double pinv,
+                                                   std::integer_sequence<int, I...>) {
+    if constexpr (PIN) {
+        double v[sizeof...(I)] = {x[GsNthBit<MASK, I>::value]...};
+        reduce_n<(int)sizeof...(I)>(v, p, pinv);
+        ((x[GsNthBit<MASK, I>::value] = v[I]), ...);
+    } else {
+        ((x[GsNthBit<MASK, I>::value] = reduce(x[GsNthBit<MASK, I>::value], p, pinv)), ...);
+    }
+}
+// PIN: phase by phase behind scheduling barriers (reduce_n); otherwise left to the compiler's scheduler
+template <unsigned MASK, bool PIN = true>
+__device__ __forceinline__ void reduce_masked(double (&x)[8], double p, double pinv) {
+    if constexpr (MASK != 0u)
+        reduce_masked_impl<MASK, PIN>(x, p, pinv, std::make_integer_sequence<int, gs_popcount(MASK)>{});
+}
+
 // Register pairs and twiddle slots of one radix-2 stage on the 8 registers of a lane.
 // D = 4, 2, 1 is the register distance; butterfly j in 0..3 pairs (lo(j), lo(j) + D) and uses
 // slot(j) of a Tw7-ordered twiddle array: [0] for D = 4, [1 + h] for D = 2, [3 + g] for D = 1.
@@ -256,6 +347,22 @@ __device__ __forceinline__ void gs8_pinned(double (&x)[8], const double* w, cons
     gs_stage_pinned<1>(x, w, wp, p);
     gs_stage_pinned<2>(x, w, wp, p);
     gs_stage_pinned<4>(x, w, wp, p);
+}
+
+// Group G (2 = layout C, 1 = layout B, 0 = layout A) of the length-512 inverse transform with the
+// reductions of its plan: those before each stage and, for G > 0, those before the transposition
+// that follows.  Outputs of the transform: below 3.2 p.
+constexpr GsPlan kGsPlan512 = make_gs_plan(3, 3);
+static_assert(kGsPlan512.out <= 4.0, "to_torus assumes outputs below 4 p");
+template <int G>
+__device__ __forceinline__ void gs8_planned(double (&x)[8], const double* w, const double* wp, double p, double pinv) {
+    reduce_masked<kGsPlan512.pre[G][0]>(x, p, pinv);
+    gs_stage_pinned<1>(x, w, wp, p);
+    reduce_masked<kGsPlan512.pre[G][1]>(x, p, pinv);
+    gs_stage_pinned<2>(x, w, wp, p);
+    reduce_masked<kGsPlan512.pre[G][2]>(x, p, pinv);
+    gs_stage_pinned<4>(x, w, wp, p);
+    reduce_masked<kGsPlan512.carry[G]>(x, p, pinv);
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -472,23 +579,17 @@ __device__ __forceinline__ void ntt512_inverse2(double (&a)[8], double (&b)[8], 
     const double p = u.p, pinv = u.pinv;
     Tw7 t;
     load_tw7(t, s_tw + kTwInvC + 7 * lane);
-    reduce_n<8>(a, p, pinv);
-    gs8_pinned(a, t.w, t.wp, p);
+    gs8_planned<2>(a, t.w, t.wp, p, pinv);
     transpose_c_to_b(a, tra, lane);
-    reduce_n<8>(b, p, pinv);
-    gs8_pinned(b, t.w, t.wp, p);
+    gs8_planned<2>(b, t.w, t.wp, p, pinv);
     transpose_c_to_b(b, trb, lane);
     load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
-    reduce_n<8>(a, p, pinv);
-    gs8_pinned(a, t.w, t.wp, p);
+    gs8_planned<1>(a, t.w, t.wp, p, pinv);
     transpose_b_to_a(a, tra, lane);
-    reduce_n<8>(b, p, pinv);
-    gs8_pinned(b, t.w, t.wp, p);
+    gs8_planned<1>(b, t.w, t.wp, p, pinv);
     transpose_b_to_a(b, trb, lane);
-    reduce_n<8>(a, p, pinv);
-    gs8_pinned(a, u.iw + 1, u.iwp + 1, p);
-    reduce_n<8>(b, p, pinv);
-    gs8_pinned(b, u.iw + 1, u.iwp + 1, p);
+    gs8_planned<0>(a, u.iw + 1, u.iwp + 1, p, pinv);
+    gs8_planned<0>(b, u.iw + 1, u.iwp + 1, p, pinv);
 }
 
 // ntt512_inverse<true> with two pieces of the caller's independent work placed where a
@@ -499,18 +600,15 @@ __device__ __forceinline__ void ntt512_inverse_overlapped(double (&x)[8], const 
                                                           int lane, A1 after1, A2 after2) {
     const double p = u.p, pinv = u.pinv;
     Tw7 t;
-    reduce_n<8>(x, p, pinv);
     load_tw7(t, s_tw + kTwInvC + 7 * lane);
-    gs8_pinned(x, t.w, t.wp, p);
+    gs8_planned<2>(x, t.w, t.wp, p, pinv);
     transpose_c_to_b(x, tr, lane);
     load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
     after1();
-    reduce_n<8>(x, p, pinv);
-    gs8_pinned(x, t.w, t.wp, p);
+    gs8_planned<1>(x, t.w, t.wp, p, pinv);
     transpose_b_to_a(x, tr, lane);
     after2();
-    reduce_n<8>(x, p, pinv);
-    gs8_pinned(x, u.iw + 1, u.iwp + 1, p);
+    gs8_planned<0>(x, u.iw + 1, u.iwp + 1, p, pinv);
 }
 
 // Inverse transform without the 1/N factor.  In: layout C, |x| < 2^53.  Out: layout A,
@@ -522,16 +620,13 @@ __device__ __forceinline__ void ntt512_inverse(double (&x)[8], const NttUniform&
     const double p = u.p, pinv = u.pinv;
     Tw7 t;
     if (PIN) {
-        reduce_n<8>(x, p, pinv);
         load_tw7(t, s_tw + kTwInvC + 7 * lane);
-        gs8_pinned(x, t.w, t.wp, p);
+        gs8_planned<2>(x, t.w, t.wp, p, pinv);
         transpose_c_to_b(x, tr, lane);
-        reduce_n<8>(x, p, pinv);
         load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
-        gs8_pinned(x, t.w, t.wp, p);
+        gs8_planned<1>(x, t.w, t.wp, p, pinv);
         transpose_b_to_a(x, tr, lane);
-        reduce_n<8>(x, p, pinv);
-        gs8_pinned(x, u.iw + 1, u.iwp + 1, p);
+        gs8_planned<0>(x, u.iw + 1, u.iwp + 1, p, pinv);
         return;
     }
 #pragma unroll

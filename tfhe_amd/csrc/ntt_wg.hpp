@@ -26,7 +26,8 @@ struct WgNtt {
     static constexpr int T = N / 8;                  // threads per polynomial
     static constexpr int GROUPS = (LOGN + 2) / 3;
     static constexpr int LAST = LOGN - 3 * (GROUPS - 1);  // stages in the last group: 1, 2 or 3
-    static constexpr int PAD = N + N / 8;            // transpose buffer, one pad slot per 8 positions
+    // block transpose buffer: one pad slot per 8 positions, none for LOGN = 11 (see block_pos)
+    static constexpr int PAD = LOGN == 11 ? N : N + N / 8;
     // A transpose between two layouts whose bases are both <= 6 moves data only inside a wave: the
     // thread bits from 6 up are position bits from 9 up in both, so wave v holds positions
     // [512 v, 512 v + 512) before and after.  Such a transpose goes through the wave's own buffer
@@ -51,6 +52,30 @@ struct WgNtt {
         return ((t >> b) << (b + 3)) | (k << b) | (t & ((1 << b) - 1));
     }
 
+    // Twiddle rows kept in LDS by kernels that have room (the rest is read from L1 / L2): level 1 = group 1
+    // of both directions (T >> base(1) rows each, every row shared by 2^base(1) threads), level 2 = also
+    // group 2 of the forward direction.  Layout: [forward group 1][inverse group 1][forward group 2].
+    __host__ __device__ static constexpr int lds_row_pairs(int level) {
+        return level == 0 ? 0 : 7 * (2 * rows(1) + (level >= 2 ? rows(2) : 0));
+    }
+    template <int LEVEL>
+    __device__ static __forceinline__ void stage_rows(d2* lds, const d2* __restrict__ table, int t) {
+        if (LEVEL == 0) return;
+        for (int e = t; e < 7 * rows(1); e += T) {
+            lds[e] = table[7 * row_offset(1) + e];
+            lds[7 * rows(1) + e] = table[7 * TABLE_ROWS + 7 * row_offset(1) + e];
+        }
+        if (LEVEL >= 2)
+            for (int e = t; e < 7 * rows(2); e += T) lds[14 * rows(1) + e] = table[7 * row_offset(2) + e];
+    }
+    // rows of group g (>= 1) of direction dir (0 forward, 1 inverse)
+    template <int LEVEL>
+    __device__ static __forceinline__ const d2* group_rows(const d2* __restrict__ table, const d2* lds, int dir, int g) {
+        if (LEVEL >= 1 && g == 1) return lds + dir * 7 * rows(1);
+        if (LEVEL >= 2 && g == 2 && dir == 0) return lds + 14 * rows(1);
+        return table + dir * 7 * TABLE_ROWS + 7 * row_offset(g);
+    }
+
     // Identity the optimiser cannot see through.  The twiddle rows are loop-invariant in a blind
     // rotation; without this their loads are hoisted out of the step loop and every group's 28
     // registers stay live for the whole kernel (168 registers, which costs the second workgroup
@@ -73,6 +98,14 @@ struct WgNtt {
         load_tw7(tw, rows + 7 * (TFHE_AMD_WG_EXPERIMENT == 1 ? opaque(0) : row));
     }
 
+    // Slot of position j in a block buffer.  The block-level transposition pairs group 0 (a wave's
+    // lanes on 64 consecutive positions) with group 1 (32-lane halves on 2^b consecutive positions,
+    // b = base(1)).  For LOGN = 11 the halves of a wave are 256 positions = 2 KiB apart, every access of
+    // either layout is a run of consecutive doubles, and any padding only makes the ends of a run
+    // collide; for LOGN = 10 the 16-lane quarters of group 1 are 1 KiB apart and need the pad slot
+    // per 8 positions to land on different banks.
+    __device__ static __forceinline__ int block_pos(int j) { return LOGN == 11 ? j : pad_pos(j); }
+
     // registers in layout `from` -> registers in layout `to`.  bufs: BUF_DOUBLES doubles; `parity`
     // selects the block buffer and is advanced once per block-level transpose.
     __device__ static __forceinline__ void transpose(double (&x)[8], double* bufs, int& parity, int from, int to, int t) {
@@ -89,10 +122,10 @@ struct WgNtt {
         double* buf = bufs + (parity & 1) * PAD;
         parity++;
 #pragma unroll
-        for (int k = 0; k < 8; k++) buf[pad_pos(position(from, t, k))] = x[k];
+        for (int k = 0; k < 8; k++) buf[block_pos(position(from, t, k))] = x[k];
         if (TFHE_AMD_WG_EXPERIMENT != 3) __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = buf[pad_pos(position(to, t, k))];
+        for (int k = 0; k < 8; k++) x[k] = buf[block_pos(position(to, t, k))];
     }
 
     template <int STAGES, bool REDUCE_A>
@@ -120,19 +153,38 @@ struct WgNtt {
         }
     }
 
-    template <int STAGES>
-    __device__ static __forceinline__ void gs_group(double (&x)[8], const Tw7& tw, double p) {
+    // lazy reductions of the inverse transform: the compile-time plan of ntt512.hpp for this ring's
+    // stage groups (register k of a thread has a bound that depends on k alone)
+    // N = 1024 keeps the plain scheme (all eight registers reduced at every group start, written as
+    // one loop over the groups): its kernels sit at the 256-register limit, and the planned form,
+    // although it executes 12 reductions fewer per transform, makes the compiler spill more there
+    // (measured: 1024/K=1/L=2 4 % slower, K=2 1.5 % slower; N = 512 and N = 2048 0.7 - 0.8 % faster).
+    static constexpr bool kPlanned = LOGN != 10;
+    static constexpr GsPlan kInversePlan = make_gs_plan(GROUPS, LAST, !kPlanned);
+    static_assert(kInversePlan.out <= 4.0, "the callers of the inverse transform assume outputs below 4 p");
+    template <int G, int S>
+    static constexpr unsigned pre_mask() { return kInversePlan.pre[G][S]; }
+    template <int G>
+    static constexpr unsigned carry_mask() { return kInversePlan.carry[G]; }
+
+    // the STAGES stages of inverse group G (twiddles in tw: [3..6] first stage, [1..2] second, [0] third)
+    template <int G, int STAGES>
+    __device__ static __forceinline__ void gs_group(double (&x)[8], const double* w, const double* wp, double p,
+                                                    double pinv) {
+        tfhe_amd::reduce_masked<pre_mask<G, 0>(), false>(x, p, pinv);
 #pragma unroll
-        for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], tw.w[3 + g], tw.wp[3 + g], p);
+        for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], w[3 + g], wp[3 + g], p);
         if (STAGES >= 2) {
+            tfhe_amd::reduce_masked<pre_mask<G, 1>(), false>(x, p, pinv);
 #pragma unroll
             for (int h = 0; h < 2; h++)
 #pragma unroll
-                for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], tw.w[1 + h], tw.wp[1 + h], p);
+                for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], w[1 + h], wp[1 + h], p);
         }
         if (STAGES >= 3) {
+            tfhe_amd::reduce_masked<pre_mask<G, 2>(), false>(x, p, pinv);
 #pragma unroll
-            for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], tw.w[0], tw.wp[0], p);
+            for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], w[0], wp[0], p);
         }
     }
 
@@ -143,9 +195,10 @@ struct WgNtt {
     // Out: last group's layout (position 8t + k, bit-reversed spectrum order), |x| <= 3.2 p.
     // Additive inputs are reduced at the first stage of groups >= 2 (SMALL) or >= 1; the bound
     // then stays below 4.2 p at every stage for LOGN <= 12.
-    template <int SMALL, int M>
+    template <int SMALL, int M, int LDS_LEVEL = 0>
     __device__ static __forceinline__ void forward_many(double (&xs)[M][8], const NttUniform& u,
-                                                        const d2* __restrict__ table, double* bufs, int& parity, int t) {
+                                                        const d2* __restrict__ table, double* bufs, int& parity, int t,
+                                                        const d2* lds_rows = nullptr) {
         const double p = u.p, pinv = u.pinv;
 #pragma unroll
         for (int m = 0; m < M; m++) {
@@ -194,7 +247,7 @@ struct WgNtt {
             // the top of the transform
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
-            load_row(tw, table + 7 * row_offset(g), opaque(t >> base(g)), u);
+            load_row(tw, group_rows<LDS_LEVEL>(table, lds_rows, 0, g), opaque(t >> base(g)), u);
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 transpose(xs[m], bufs, parity, g - 1, g, t);
@@ -219,23 +272,53 @@ struct WgNtt {
 
     // M inverse transforms without the 1/N factor, group by group, so that every group's twiddle
     // row is loaded once for all of them.  In: last group's layout, |x| < 2^53.  Out: group-0
-    // layout, |x| <= 4 p.  Every group starts from |x| <= p/2.
-    template <int M>
-    __device__ static __forceinline__ void inverse_many(double (&x)[M][8], const NttUniform& u,
-                                                        const d2* __restrict__ table, double* bufs, int& parity, int t) {
+    // layout, |x| <= 4 p (kInversePlan.out).  Reductions: kInversePlan.
+    template <int G, int M, int LDS_LEVEL>
+    __device__ static __forceinline__ void inverse_group(double (&x)[M][8], const NttUniform& u,
+                                                         const d2* __restrict__ table, const d2* lds_rows, double* bufs,
+                                                         int& parity, int t) {
         const double p = u.p, pinv = u.pinv;
-        const d2* inv_table = table + 7 * TABLE_ROWS;
+        __builtin_amdgcn_sched_barrier(0);
+        Tw7 tw;
+        load_row(tw, group_rows<LDS_LEVEL>(table, lds_rows, 1, G), opaque(t >> base(G)), u);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            gs_group<G, stages(G)>(x[m], tw.w, tw.wp, p, pinv);
+            tfhe_amd::reduce_masked<carry_mask<G>(), false>(x[m], p, pinv);
+            transpose(x[m], bufs, parity, G, G - 1, t);
+        }
+    }
+    template <int STAGES>
+    __device__ static __forceinline__ void gs_group_plain(double (&x)[8], const Tw7& tw, double p) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) bf_gs(x[2 * g], x[2 * g + 1], tw.w[3 + g], tw.wp[3 + g], p);
+        if (STAGES >= 2) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k = 0; k < 2; k++) bf_gs(x[4 * h + k], x[4 * h + k + 2], tw.w[1 + h], tw.wp[1 + h], p);
+        }
+        if (STAGES >= 3) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) bf_gs(x[k], x[k + 4], tw.w[0], tw.wp[0], p);
+        }
+    }
+    template <int M, int LDS_LEVEL>
+    __device__ static __forceinline__ void inverse_many_plain(double (&x)[M][8], const NttUniform& u,
+                                                              const d2* __restrict__ table, double* bufs, int& parity,
+                                                              int t, const d2* lds_rows) {
+        const double p = u.p, pinv = u.pinv;
 #pragma unroll
         for (int g = GROUPS - 1; g >= 1; g--) {
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
-            load_row(tw, inv_table + 7 * row_offset(g), opaque(t >> base(g)), u);
+            load_row(tw, group_rows<LDS_LEVEL>(table, lds_rows, 1, g), opaque(t >> base(g)), u);
 #pragma unroll
             for (int m = 0; m < M; m++) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) x[m][k] = reduce(x[m][k], p, pinv);
-                if (g == GROUPS - 1) gs_group<LAST>(x[m], tw, p);
-                else                 gs_group<3>(x[m], tw, p);
+                if (g == GROUPS - 1) gs_group_plain<LAST>(x[m], tw, p);
+                else                 gs_group_plain<3>(x[m], tw, p);
                 transpose(x[m], bufs, parity, g, g - 1, t);
             }
         }
@@ -252,6 +335,22 @@ struct WgNtt {
 #pragma unroll
             for (int k = 0; k < 4; k++) bf_gs(x[m][k], x[m][k + 4], u.iw[1], u.iwp[1], p);
         }
+    }
+    template <int M, int LDS_LEVEL = 0>
+    __device__ static __forceinline__ void inverse_many(double (&x)[M][8], const NttUniform& u,
+                                                        const d2* __restrict__ table, double* bufs, int& parity, int t,
+                                                        const d2* lds_rows = nullptr) {
+        if constexpr (!kPlanned) {
+            inverse_many_plain<M, LDS_LEVEL>(x, u, table, bufs, parity, t, lds_rows);
+            return;
+        }
+        static_assert(GROUPS == 3 || GROUPS == 4, "groups 1 .. GROUPS-1 are written out below");
+        if constexpr (GROUPS == 4) inverse_group<3, M, LDS_LEVEL>(x, u, table, lds_rows, bufs, parity, t);
+        inverse_group<2, M, LDS_LEVEL>(x, u, table, lds_rows, bufs, parity, t);
+        inverse_group<1, M, LDS_LEVEL>(x, u, table, lds_rows, bufs, parity, t);
+        // group 0: thread-uniform twiddles u.iw[1 .. 7], laid out like a table row shifted by one
+#pragma unroll
+        for (int m = 0; m < M; m++) gs_group<0, 3>(x[m], u.iw + 1, u.iwp + 1, u.p, u.pinv);
     }
 
     __device__ static __forceinline__ void inverse(double (&x)[8], const NttUniform& u, const d2* __restrict__ table,

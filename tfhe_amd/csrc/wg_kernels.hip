@@ -68,6 +68,9 @@ bk_transform_wg_kernel(const NttUniform u, const d2* __restrict__ table, const u
 // transpose barrier the other one computes.  Measured alternatives: one workgroup per CU with
 // the L digit transforms of a polynomial interleaved in each wave (more parallelism per wave,
 // fewer barriers) is 20 % slower, three workgroups per CU spill and are 35 % slower.
+#ifndef TFHE_AMD_WG_LDS_ROWS
+#define TFHE_AMD_WG_LDS_ROWS -1  // experiment switch: 0, 1 or 2 forces the level for every instantiation
+#endif
 template <int LOGN, int K, int L, int BG, int PACK>
 __global__ void __launch_bounds__(WgNtt<LOGN>::T, 2)
 blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d2* __restrict__ bk_ntt,
@@ -77,13 +80,17 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
     constexpr int N = W::N, T = W::T, K1 = K + 1, R = K1 * L;
     constexpr int PACKS = (K1 + PACK - 1) / PACK, TILES = K1 + PACKS, SMALL = BG == 8 ? 1 : 2;
     static_assert((BG == 8 || BG == 16) && L * BG <= 31 && (PACK == 1 || PACK == 2), "gadget shape");
+    // twiddle rows in LDS as far as two workgroups per CU leave room (80 KB each)
+    constexpr int ROWS_IN_LDS = TFHE_AMD_WG_LDS_ROWS < 0 ? (LOGN == 11 ? (K1 == 2 ? 2 : 1) : 0) : TFHE_AMD_WG_LDS_ROWS;
     __shared__ double s_tr[W::BUF_DOUBLES];
     __shared__ uint32_t s_acc[K1][N];
+    __shared__ d2 s_rows[W::lds_row_pairs(ROWS_IN_LDS) > 0 ? W::lds_row_pairs(ROWS_IN_LDS) : 1];
     const int t = threadIdx.x;
     const size_t gate = blockIdx.x;
     const uint32_t* cg = c + gate * (size_t)(n + 1);
     const double p = u.p, pinv = u.pinv;
     constexpr int SH = 32 - (LOGN + 1);
+    W::template stage_rows<ROWS_IN_LDS>(s_rows, table, t);
 
     {
         const int bbar = (int)(cg[0] >> SH);
@@ -142,7 +149,7 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             for (int level = 0; level < L; level++)
 #pragma unroll
                 for (int k = 0; k < 8; k++) x[level][k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
-            W::template forward_many<SMALL, L>(x, u, table, s_tr, parity, t);  // |x| <= 3.2 p
+            W::template forward_many<SMALL, L, ROWS_IN_LDS>(x, u, table, s_tr, parity, t, s_rows);  // |x| <= 3.2 p
 #pragma unroll
             for (int level = 0; level < L; level++) {
 #pragma unroll
@@ -176,7 +183,7 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             }
         }
         // all K1 + PACKS inverse transforms group by group: one load of every twiddle row serves them all
-        W::template inverse_many<TILES>(acc_ntt, u, table, s_tr, parity, t);
+        W::template inverse_many<TILES, ROWS_IN_LDS>(acc_ntt, u, table, s_tr, parity, t, s_rows);
 #pragma unroll
         for (int col = 0; col < K1; col++) {
             // the packed accumulator holds the small exact hi sums of two columns: h_even + 2^pack_shift h_odd
