@@ -1,6 +1,8 @@
 """Condense the rocprofv3 --pmc dumps written by tools/pmc_passes.sh into one JSON per round.
 
-  python3 tools/pmc_summarize.py <tag>     reads gpurun_out/pmc_<tag>*/, writes profiles/<tag>_pmc_summary.json
+  python3 tools/pmc_summarize.py <tag> [name]   reads gpurun_out/pmc_<tag>*/, writes profiles/<name>_pmc_summary.json
+                                                (name defaults to tag); refuses to write a summary without the
+                                                default workload's kernels
 
 Per-launch averages of every counter for every kernel of the library that ran (kernel names shortened to
 the function name); the default workload's kernels at the top level under "kernels", the other
@@ -14,6 +16,7 @@ import re
 import sys
 
 tag = sys.argv[1]
+name = sys.argv[2] if len(sys.argv) > 2 else tag
 
 
 def short(name):
@@ -55,5 +58,7 @@ out = {"command": "rocprofv3 --pmc <counters> --output-format csv -- python3 too
 for d in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*")):
     if os.path.isdir(d):
         out["other_workloads"][d.split(f"pmc_{tag}_", 1)[1]] = summarize(d)
-json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+if not out["kernels"]:
+    sys.exit(f"no counter dumps under gpurun_out/pmc_{tag}: nothing written")
+json.dump(out, open(f"profiles/{name}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: sorted(v) for k, v in [("kernels", out["kernels"])] + list(out["other_workloads"].items())}, indent=1))
