@@ -221,7 +221,7 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
     constexpr int K1 = K + 1, R = K1 * L, BG = 8, M = 256;
     __shared__ d2 s_rows[2 * kFftRows * 3];
     __shared__ d2 s_untwist[M];  // natural order
-    __shared__ double s_tr[4][2][2 * kHalfTrWords];
+    __shared__ d2 s_tr[4][2][kHalfTrWords];
     __shared__ uint32_t s_acc[4][K1][kN];
 
     for (int i = threadIdx.x; i < 2 * kFftRows * 3; i += 256) s_rows[i] = tables[4 * M + i];
@@ -231,8 +231,8 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gate = blockIdx.x * 4 + wave;
     if (gate >= n_gates) return;  // waves are independent from here on
-    double* tr0 = s_tr[wave][0];
-    double* tr1 = s_tr[wave][1];
+    d2* tr0 = s_tr[wave][0];
+    d2* tr1 = s_tr[wave][1];
     uint32_t(*acc)[kN] = s_acc[wave];
     const uint32_t* cg = c + (size_t)gate * (n + 1);
     const d2* rows_fwd = s_rows + kFftFwdRows;
