@@ -90,7 +90,7 @@ def test_plan_keeps_every_butterfly_exact(index):
     # 4 p up to the rounding allowance of eight reduced values (the plain scheme of N = 1024 is exactly there)
     assert out <= 4 + 8 * EPS, f"N = 2^{log2n}: outputs reach {float(out):.4f} p"
     # the planner works with 5.26 for 2^53 / p and a larger rounding allowance: its own bound is the looser one
-    assert float(out) <= claimed + 1e-9
+    assert float(out) <= claimed + 1e-6
 
 
 def test_limit_constant_is_conservative():
