@@ -200,20 +200,28 @@ std::vector<double> build_tw_block_512(const TwiddleSet& t) {
     fill(kTwFwdC, 64, 64, t.fwd);
     fill(kTwInvB, 8, 8, t.inv);
     fill(kTwInvC, 64, 64, t.inv);
-    // table of the two-wave transform (ntt512_half.hpp), appended: forward rows, then inverse rows;
-    // group g starts at stage 2g - 1 with m = 2^(2g-1) rows [tab[m + U], tab[2m + 2U], tab[2m + 2U + 1]]
-    for (int dir = 0; dir < 2; dir++) {
-        const std::vector<uint64_t>& tab = dir ? t.inv : t.fwd;
-        for (int g = 1; g <= 4; g++) {
-            const int m = 1 << (2 * g - 1);
-            for (int U = 0; U < m; U++) {
-                const int pair = kTwPairs + 3 * (dir * kHalfRows + half_row_offset(g) + U);
-                put(pair, tab[m + U]);
-                put(pair + 1, tab[2 * m + 2 * U]);
-                put(pair + 2, tab[2 * m + 2 * U + 1]);
-            }
+    // table of the two-wave transforms (ntt512_half.hpp), appended.  Forward rows: group g starts at stage
+    // 2g - 1 with m = 2^(2g-1) rows [tab[m + U], tab[2m + 2U], tab[2m + 2U + 1]]
+    for (int g = 1; g <= 4; g++) {
+        const int m = 1 << (2 * g - 1);
+        for (int U = 0; U < m; U++) {
+            const int pair = kTwPairs + 3 * (half_row_offset(g) + U);
+            put(pair, t.fwd[m + U]);
+            put(pair + 1, t.fwd[2 * m + 2 * U]);
+            put(pair + 2, t.fwd[2 * m + 2 * U + 1]);
         }
     }
+    // parity-split inverse: first-stage twiddles [k][lane], then rows of the same shape for m = 64, 16, 4, 1
+    const int par = kTwPairs + 3 * kHalfRows;
+    for (int k = 0; k < 4; k++)
+        for (int l = 0; l < 64; l++) put(par + 64 * k + l, t.inv[256 + 4 * l + k]);
+    for (int m = 64; m >= 1; m /= 4)
+        for (int U = 0; U < m; U++) {
+            const int pair = par + 256 + 3 * (parity_row_offset(m) + U);
+            put(pair, t.inv[m + U]);
+            put(pair + 1, t.inv[2 * m + 2 * U]);
+            put(pair + 2, t.inv[2 * m + 2 * U + 1]);
+        }
     return blk;
 }
 

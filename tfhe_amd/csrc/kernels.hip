@@ -475,34 +475,40 @@ external_product_512_kernel(const NttUniform u, const d2* __restrict__ tw, const
 }
 
 // ------------------------------------------------------------------------------------------
-// Blind rotation for small batches (latency form).  One WORKGROUP owns one gate; every
-// length-512 transform is split over two waves (ntt512_half.hpp), so a step is spread over
-// 2 (K+1) L = 12 waves, three per SIMD:
+// Blind rotation for small batches (latency form).  One WORKGROUP owns one gate; every forward
+// transform is split over two waves by halves of the vector and every inverse transform by the parity
+// of the position (ntt512_half.hpp), so a step is spread over 2 (K+1) L = 12 waves, three per SIMD:
 //   phase 1: wave (r, h) decomposes digit polynomial r, transforms half h of it and multiplies
-//            with half h of key row r (partial products to LDS);
-//   phase 2: wave (col, h) sums the partial products of half h of column col and
-//            inverse-transforms them up to the last stage;
-//   phase 3: the last stage pairs the two halves through LDS and updates the accumulator, two
-//            registers of one half column per wave (all twelve waves).
+//            with half h of key row r.  Its lanes hold both inputs of two first-stage butterflies
+//            of the inverse transform per column; that stage is linear and commutes with the
+//            summation over r, so the wave stores the sum and the difference of each such pair of
+//            partial products;
+//   phase 2: wave (col, e) adds up the partial sums (e = 0) or differences (e = 1) of column col,
+//            finishes the first stage (e = 1: one twiddle product), runs the other eight stages
+//            alone and updates the accumulator coefficients of parity e.  No stage pairs the two
+//            waves.
 // Against one wave per gate (blind_rotate_512_kernel) the dependent chain of a step is one half
 // forward transform, one multiply and one half inverse transform instead of six, eighteen and
-// three whole ones, and all four SIMDs carry the same load in phase 1 (a variant with one wave per
-// transform, six waves, measured 2.74 ms per gate against 2.46 ms for this one).  Same arithmetic,
-// same results.  `tw_half`: the table of ntt512_half.hpp.
+// three whole ones, and all four SIMDs carry the same load in phase 1.  Two block barriers per step
+// (a form whose inverse was split by halves of the vector needed a third phase for the stage
+// that pairs the halves: 2.31 ms per gate against 2.26 ms; six waves, one per transform: 2.74 ms).
+// Same arithmetic, same results.  `tw_half`: the table of ntt512_half.hpp.
 // ------------------------------------------------------------------------------------------
 template <int K, int L>
 __global__ void __launch_bounds__(128 * (K + 1) * L, 1)
 blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_half, const d2* __restrict__ bk_ntt,
-                              const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv,
-                              uint32_t* __restrict__ out, int n_gates, int n, int extract) {
+                               const uint32_t* __restrict__ c, const uint32_t* __restrict__ tv,
+                               uint32_t* __restrict__ out, int n_gates, int n, int extract) {
     constexpr int K1 = K + 1, R = K1 * L, BG = 8, WAVES = 2 * R, THREADS = 64 * WAVES;
+    constexpr int FWD = 3 * kHalfRows;  // forward rows of the table; the inverse part follows
     __shared__ d2 s_tw[kHalfPairs];
     __shared__ double s_tr[WAVES][kHalfTrWords];
     __shared__ uint32_t s_acc[K1][kN];
-    __shared__ double s_part[R][K1][kN];  // [digit polynomial][column][256 h + 64 k + lane]
-    __shared__ double s_x[K1][kN];        // inverse halves before the last stage, [column][256 h + 64 k + lane]
+    __shared__ d2 s_part[R][K1][2][kPairSlots / 2];  // [digit polynomial][column][sum | difference][pair index i, padded]
 
     for (int i = threadIdx.x; i < kHalfPairs; i += THREADS) s_tw[i] = tw_half[i];
+    const d2* s_first = s_tw + FWD;       // [4][64] first-stage twiddles of the inverse
+    const d2* s_rows = s_tw + FWD + 256;  // rows of its other stages
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = w >> 1, h = w & 1;
     const int gate = blockIdx.x;
@@ -532,6 +538,9 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
     // This wave's share of a key polynomial: spectrum positions 256 h + 4 lane + k, i.e. pairs
     // kk = 2 (lane & 1) + {0, 1} of lane 32 h + (lane >> 1) in the stored [4][64][2] order.
     const int key_off = (2 * (lane & 1)) * 64 + 32 * h + (lane >> 1);
+    // Phase 1 holds positions 256 h + 4 lane + k, i.e. the first-stage pairs i = 128 h + 2 lane + {0, 1};
+    // phase 2 wants i = 4 lane + k.
+    const int put_at = pair_slot(128 * h + 2 * lane) / 2, get_at = pair_slot(4 * lane) / 2;
     d2 y[K1][2], ynext[K1][2];
     {
         const d2* bk_poly = bk_ntt + (size_t)r * K1 * (kN / 2) + key_off;
@@ -571,51 +580,54 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
         double x[4];
         half_forward_small(x, d, h, u, s_tw, tr, lane);  // |x| <= 2.2 p
 #pragma unroll
-        for (int col = 0; col < K1; col++)
+        for (int col = 0; col < K1; col++) {
+            double pr[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const double yk = (k & 1) ? y[col][k >> 1].y : y[col][k >> 1].x;
-                s_part[r][col][256 * h + 64 * k + lane] = mulmod_var(x[k], yk, p, pinv);  // <= 1.13 p
+                pr[k] = mulmod_var(x[k], yk, p, pinv);  // <= 1.13 p
             }
-        __syncthreads();
-
-        // ---- phase 2: half h of column r (waves with r <= K) ----
-        // Phase 3 is spread over all waves: wave (r, h) finishes registers 2 p3, 2 p3 + 1 of half h of
-        // column c3, where (c3, p3) = (r, 0) for the waves that ran phase 2 and (r - (K+1), 1) for
-        // the others.  The accumulator words a wave will update (nobody else writes them) are fetched
-        // here so that phase 3 has one LDS round trip less.
-        const int c3 = r < K1 ? r : r - K1, p3 = r < K1 ? 0 : 1;
-        uint32_t acc_old[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) acc_old[k] = s_acc[c3][256 * h + 64 * (2 * p3 + k) + lane];
-        if (r < K1) {
-            double sum[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) sum[k] = 0.0;
-#pragma unroll
-            for (int rr = 0; rr < R; rr++) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) sum[k] += s_part[rr][r][256 * h + 64 * k + lane];
-                // reduce after every third product: the running sum stays below 0.5 p + 3 * 1.13 p
-                if (rr % 3 == 2 && rr != R - 1) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) sum[k] = reduce(sum[k], p, pinv);
-                }
-            }
-            half_inverse(sum, h, u, s_tw + 3 * kHalfRows, tr, lane);  // |sum| <= 2 p
-#pragma unroll
-            for (int k = 0; k < 4; k++) s_x[r][256 * h + 64 * k + lane] = sum[k];
+            s_part[r][col][0][put_at] = d2{pr[0] + pr[1], pr[2] + pr[3]};  // <= 2.26 p
+            s_part[r][col][1][put_at] = d2{pr[0] - pr[1], pr[2] - pr[3]};
         }
         __syncthreads();
 
-        // ---- phase 3: last stage (distance 256, twiddle index 1) and accumulator update ----
-        static_assert(R == 2 * K1, "phase 3 gives every wave two registers of one half column");
+        // ---- phase 2: parity e = h of column r (waves with r <= K) ----
+        if (r < K1) {
+            const int e = h;
+            uint32_t acc_old[4];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int j = 64 * (2 * p3 + k) + lane;
-            const double a = s_x[c3][j], b = s_x[c3][256 + j];
-            const double v = h ? mulmod_tw(a - b, u.iw[1], u.iwp[1], p) : a + b;
-            s_acc[c3][256 * h + j] = acc_old[k] + to_torus(v, p, pinv);
+            for (int k = 0; k < 4; k++) acc_old[k] = s_acc[r][128 * k + 2 * lane + e];
+            double x2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) x2[k] = 0.0;
+            static_assert(R % 2 == 0, "the sums below are reduced after every second term");
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                const d2 v0 = s_part[rr][r][e][get_at], v1 = s_part[rr][r][e][get_at + 1];
+                x2[0] += v0.x;
+                x2[1] += v0.y;
+                x2[2] += v1.x;
+                x2[3] += v1.y;
+                // the running sum stays below 0.5 p + 2 * 2.26 p = 5.02 p < 2^53
+                if ((rr & 1) && rr != R - 1) reduce_n<4>(x2, p, pinv);
+            }
+            if (e == 0) {
+                reduce_n<4>(x2, p, pinv);
+            } else {
+                double df[4], ww[4], wwp[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    df[k] = x2[k];
+                    const d2 t1 = s_first[64 * k + lane];
+                    ww[k] = t1.x;
+                    wwp[k] = t1.y;
+                }
+                mulmod_tw_n<4>(x2, df, ww, wwp, p);  // <= 1.22 p
+            }
+            parity_inverse(x2, u, s_rows, tr, lane);  // <= 2.2 p, position 128 k + 2 lane + e
+#pragma unroll
+            for (int k = 0; k < 4; k++) s_acc[r][128 * k + 2 * lane + e] = acc_old[k] + to_torus(x2[k], p, pinv);
         }
         __syncthreads();
     }

@@ -1,9 +1,10 @@
 // The length-512 negacyclic NTT of ntt512.hpp split over TWO waves, for the latency form of the
-// blind rotation: after the first radix-2 stage (distance 256) the two halves of the vector are
+// blind rotation.
+// Forward: after the first radix-2 stage (distance 256) the two halves of the vector are
 // independent length-256 transforms, so wave h in {0, 1} computes stage 0 for its own half from
 // the (cheap, 8-bit) inputs and then owns positions 256 h .. 256 h + 255: 4 coefficients per lane,
 // four groups of two radix-2 stages in registers, two transposes through a private LDS buffer and
-// one in registers.
+// one in registers.  Inverse: split by the parity of the position instead (second part of this file).
 // Same field, same modular arithmetic, same spectrum order as ntt512.hpp: the half-h wave ends
 // with spectrum positions 256 h + 4 lane + k, which in the full transform's layout C
 // (position 8 l + k) are lane l = 32 h + (lane >> 1), registers 4 (lane & 1) + k.
@@ -26,9 +27,8 @@ struct Tw3 {
     double w[3], wp[3];  // [0] first stage of the group (both butterflies), [1..2] second stage
 };
 
-constexpr int kHalfRows = 2 + 8 + 32 + 128;    // groups 1..4, both halves
-constexpr int kHalfPairs = 2 * kHalfRows * 3;  // forward rows, then inverse rows
-constexpr int kHalfTrWords = 320;              // private transpose buffer, doubles per wave
+constexpr int kHalfRows = 2 + 8 + 32 + 128;  // groups 1..4, both halves
+constexpr int kHalfTrWords = 320;            // private transpose buffer, doubles per wave
 
 __host__ __device__ constexpr int half_row_offset(int g) { return g == 1 ? 0 : (g == 2 ? 2 : (g == 3 ? 10 : 42)); }
 
@@ -197,33 +197,69 @@ __device__ __forceinline__ void half_forward_small(double (&x)[4], const double 
     ct4<true>(x, t, p, pinv);
 }
 
-// Inverse of half h up to, not including, the last stage (distance 256, which pairs the two
-// halves).  In: layout 4, |x| < 2^53.  Out: layout 1, |x| <= 2 p.  A reduction every three
-// stages keeps the sum outputs below 4 p.
-__device__ __forceinline__ void half_inverse(double (&x)[4], int h, const NttUniform& u, const d2* s_tw_inv,
-                                             double* tr, int lane) {
+// ---- inverse transform split by the parity of the position -----------------------------------------
+// A Gentleman-Sande inverse on the spectrum order above pairs positions (2i, 2i + 1) in its first stage
+// (distance 1); every later stage has an even distance, so the sums (even positions) and the twiddled
+// differences (odd positions) never meet again.  Wave e in {0, 1} therefore computes its own output
+// of every first-stage butterfly from all 512 inputs and then runs the remaining eight stages
+// (distances 2 .. 256) alone, on the 256 positions P = 2i + e; it ends with the finished time-domain
+// coefficients of its parity, and no stage is left that pairs the two waves.
+// Lane/register maps: the layouts 4 .. 1 above applied to i (layout 4: i = 4 lane + k, i.e. a lane
+// takes the eight inputs 8 lane .. 8 lane + 7; layout 1: i = 64 k + lane, output position
+// 128 k + 2 lane + e).  A stage of distance t has 256 / t blocks and block b uses inverse twiddle
+// tab[256 / t + b], the same for both parities.  Table: [4][64] first-stage twiddles
+// tab[256 + 4 lane + k] stored [k][lane], then rows [tab[m + U], tab[2m + 2U], tab[2m + 2U + 1]] for
+// m = 64 (U = lane), 16 (U = lane >> 2), 4 (U = lane >> 4), 1 (U = 0).
+constexpr int kParityRows = 64 + 16 + 4 + 1;
+constexpr int kParityPairs = 256 + 3 * kParityRows;
+constexpr int kHalfPairs = 3 * kHalfRows + kParityPairs;  // the whole table: forward rows, then the inverse part
+__host__ __device__ constexpr int parity_row_offset(int m) { return m == 64 ? 0 : (m == 16 ? 64 : (m == 4 ? 80 : 84)); }
+
+// Slot (in doubles) of first-stage pair i in a row of 256 partial sums or differences kept in LDS.  A
+// forward wave stores i = 128 h + 2 lane + {0, 1} with one 16-byte access, an inverse wave loads
+// i = 4 lane + {0, 1} and {2, 3} with two; two pad slots per 32 keep the loads of lanes l and l + 8,
+// which are 256 bytes apart without them, on different banks.
+__host__ __device__ constexpr int pair_slot(int i) { return i + 2 * (i >> 5); }
+constexpr int kPairSlots = 256 + 16;
+
+// Stages 2 .. 9 of the parity-split inverse.  In: layout 4 of i, |x| <= 1.22 p.  Out: layout 1,
+// |x| <= 2.2 p.  Bounds in units of p (a butterfly maps (a, b) to (a + b, 0.5 + 0.75 (a + b) / 5.26);
+// a transposition may hand a lane any register's value, so every group starts from the largest bound
+// left): [1.22 x 4] -> near [2.44, .85, 2.44, .85] -> far [4.88, 1.7, 1.2, .74], register 0 reduced
+// -> 1.7 -> near [3.4, .98, ..], registers 0 and 2 reduced -> far [1.0, 1.96, .64, .78] -> 1.96 ->
+// near [3.92, 1.06, ..], reduced -> far [1.0, 2.1, .64, .8] -> 2.1 -> near [4.2, 1.1, ..], reduced ->
+// far [1.0, 2.2, .64, .81].
+__device__ __forceinline__ void reduce_0_2(double (&x)[4], double p, double pinv) {
+    double a[2] = {x[0], x[2]};
+    reduce_n<2>(a, p, pinv);
+    x[0] = a[0];
+    x[2] = a[1];
+}
+__device__ __forceinline__ void parity_inverse(double (&x)[4], const NttUniform& u, const d2* s_rows, double* tr,
+                                               int lane) {
     const double p = u.p, pinv = u.pinv;
     Tw3 t;
-    reduce_n<4>(x, p, pinv);
-    load_tw3(t, s_tw_inv + 3 * (half_row_offset(4) + half_row<4>(h, lane)));
+    load_tw3(t, s_rows + 3 * (parity_row_offset(64) + lane));
     gs4_near(x, t, p);
     gs4_far(x, t, p);
+    x[0] = reduce(x[0], p, pinv);
 
     half_transpose<4, 3>(x, tr, lane);
-    load_tw3(t, s_tw_inv + 3 * (half_row_offset(3) + half_row<3>(h, lane)));
+    load_tw3(t, s_rows + 3 * (parity_row_offset(16) + (lane >> 2)));
     gs4_near(x, t, p);
-    reduce_n<4>(x, p, pinv);
+    reduce_0_2(x, p, pinv);
     gs4_far(x, t, p);
 
     half_transpose<3, 2>(x, tr, lane);
-    load_tw3(t, s_tw_inv + 3 * (half_row_offset(2) + half_row<2>(h, lane)));
+    load_tw3(t, s_rows + 3 * (parity_row_offset(4) + (lane >> 4)));
     gs4_near(x, t, p);
+    reduce_0_2(x, p, pinv);
     gs4_far(x, t, p);
 
     half_transpose_1_2(x);
-    reduce_n<4>(x, p, pinv);
-    load_tw3(t, s_tw_inv + 3 * (half_row_offset(1) + half_row<1>(h, lane)));
-    gs4_near(x, t, p);  // distance 64; the distance-128 stage follows
+    load_tw3(t, s_rows + 3 * parity_row_offset(1));
+    gs4_near(x, t, p);
+    reduce_0_2(x, p, pinv);
     gs4_far(x, t, p);
 }
 
