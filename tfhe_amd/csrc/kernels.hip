@@ -534,6 +534,7 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
         flip |= 1u << (32 - BG * (l + 1) + BG - 1);
     }
     const int q = r / L, level = r % L;
+    const unsigned digit_at = 32 - BG * (level + 1);  // lowest bit of this wave's digit
 
     // This wave's share of a key polynomial: spectrum positions 256 h + 4 lane + k, i.e. pairs
     // kk = 2 (lane & 1) + {0, 1} of lane 32 h + (lane >> 1) in the stored [4][64][2] order.
@@ -575,7 +576,7 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
             const uint32_t neg = 0u - (uint32_t)((sidx >> 9) & 1);
             const uint32_t v = s_acc[q][sidx & (kN - 1)];
             const uint32_t t = ((((v ^ neg) - neg) - s_acc[q][j]) + offset) ^ flip;
-            d[k] = (double)(((int32_t)(t << (BG * level))) >> (32 - BG));
+            d[k] = (double)(int32_t)__builtin_amdgcn_sbfe(t, digit_at, BG);  // signed digit `level`, one instruction
         }
         double x[4];
         half_forward_small(x, d, h, u, s_tw, tr, lane);  // |x| <= 2.2 p
