@@ -550,8 +550,17 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
 #pragma unroll
             for (int t = 0; t < 2; t++) ynext[col][t] = bk_poly[col * (kN / 2) + t * 64];
     }
+#ifdef TFHE_AMD_LATENCY_CLOCKS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define LPH_START() tprev = __builtin_amdgcn_s_memtime()
+#define LPH_MARK(I) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[I] += tn_ - tprev; tprev = tn_; }
+#else
+#define LPH_START()
+#define LPH_MARK(I)
+#endif
     uint32_t cvals = 0;
     for (int i = 0; i < n; i++) {
+        LPH_START();
         if ((i & 63) == 0) cvals = (i + lane < n) ? cg[1 + i + lane] : 0u;
         const uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cvals, i & 63);
         const int abar = (int)((ci + (1u << 21)) >> 22);
@@ -578,8 +587,16 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
             const uint32_t t = ((((v ^ neg) - neg) - s_acc[q][j]) + offset) ^ flip;
             d[k] = (double)(int32_t)__builtin_amdgcn_sbfe(t, digit_at, BG);  // signed digit `level`, one instruction
         }
+#ifdef TFHE_AMD_LATENCY_CLOCKS
+        asm volatile("" :: "v"(d[0]), "v"(d[7]));
+#endif
+        LPH_MARK(0)
         double x[4];
         half_forward_small(x, d, h, u, s_tw, tr, lane);  // |x| <= 2.2 p
+#ifdef TFHE_AMD_LATENCY_CLOCKS
+        asm volatile("" :: "v"(x[0]), "v"(x[3]));
+#endif
+        LPH_MARK(1)
 #pragma unroll
         for (int col = 0; col < K1; col++) {
             double pr[4];
@@ -591,7 +608,9 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
             s_part[r][col][0][put_at] = d2{pr[0] + pr[1], pr[2] + pr[3]};  // <= 2.26 p
             s_part[r][col][1][put_at] = d2{pr[0] - pr[1], pr[2] - pr[3]};
         }
+        LPH_MARK(2)
         __syncthreads();
+        LPH_MARK(3)
 
         // ---- phase 2: parity e = h of column r (waves with r <= K) ----
         if (r < K1) {
@@ -626,12 +645,27 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
                 }
                 mulmod_tw_n<4>(x2, df, ww, wwp, p);  // <= 1.22 p
             }
+#ifdef TFHE_AMD_LATENCY_CLOCKS
+            asm volatile("" :: "v"(x2[0]), "v"(x2[3]));
+#endif
+            LPH_MARK(4)
             parity_inverse(x2, u, s_rows, tr, lane);  // <= 2.2 p, position 128 k + 2 lane + e
+#ifdef TFHE_AMD_LATENCY_CLOCKS
+            asm volatile("" :: "v"(x2[0]), "v"(x2[3]));
+#endif
+            LPH_MARK(5)
 #pragma unroll
             for (int k = 0; k < 4; k++) s_acc[r][128 * k + 2 * lane + e] = acc_old[k] + to_torus(x2[k], p, pinv);
         }
+        LPH_MARK(6)
         __syncthreads();
+        LPH_MARK(7)
     }
+#ifdef TFHE_AMD_LATENCY_CLOCKS
+    if (gate == 0 && lane == 0)
+        printf("wave %2d ticks: decompose %llu forward %llu products %llu barrier %llu | sum+stage1 %llu inverse %llu update %llu barrier %llu\n",
+               w, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
+#endif
 
     if (!extract) {
         uint32_t* o = out + (size_t)gate * (K1 * kN);
