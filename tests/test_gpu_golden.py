@@ -115,15 +115,17 @@ def test_external_product_default_size_vs_oracle_and_reference_fft(golden):
     assert delta.min() >= -6 and delta.max() <= 0
 
 
-def test_extreme_operands_stay_exact():
+@pytest.mark.parametrize("K", [2, 1])
+def test_extreme_operands_stay_exact(K):
     """Worst-case magnitudes for the transform's lazy-reduction bounds: key words at the ends
     of the centred range, accumulators whose rotated difference decomposes to digits of -128
-    or +127 everywhere.  NTT kernels vs the O(N^2) wrap-around kernels vs the oracle."""
+    or +127 everywhere.  NTT kernels (both forms, K = 2 and K = 1) vs the O(N^2) wrap-around kernels vs
+    the oracle."""
     import tfhe_amd
 
     n = 6
-    p6 = tfhe_amd.Params(n, 512, 2, 8, 2, 5, 2)
-    op = O.params_from(n, 512, 2, 8, 2, 5, 2)
+    p6 = tfhe_amd.Params(n, 512, K, 8, 2, 5, 2)
+    op = O.params_from(n, 512, K, 8, 2, 5, 2)
     rs = np.random.RandomState(21)
     patterns = {
         "min": np.full(p6.bk_shape(), 0x80000000, dtype=np.uint32),
@@ -131,18 +133,23 @@ def test_extreme_operands_stay_exact():
         "alt": np.where(rs.randint(0, 2, size=p6.bk_shape()) == 1, 0x80000000, 0x7FFFFFFF).astype(np.uint32),
     }
     # test vectors that make (acc * X^a - acc) hit the digit extremes: +-2^31 steps and 0x7F7F.. runs
-    tvs = [np.full((3, 512), 0x80000000, dtype=np.uint32),
-           np.tile(np.array([0x7F7F8000, 0x80808000], dtype=np.uint32), (3, 256)),
-           rs.randint(0, 2**32, size=(3, 512), dtype=np.uint64).astype(np.uint32)]
+    tvs = [np.full((K + 1, 512), 0x80000000, dtype=np.uint32),
+           np.tile(np.array([0x7F7F8000, 0x80808000], dtype=np.uint32), (K + 1, 256)),
+           rs.randint(0, 2**32, size=(K + 1, 512), dtype=np.uint64).astype(np.uint32)]
     c = rs.randint(0, 2**32, size=(8, n + 1), dtype=np.uint64).astype(np.uint32)
     c[0, 1:] = 0x00400000  # rotate by exactly one position every step
     c[1, 1:] = 0x80000000  # rotate by N: acc * X^N = -acc, difference = -2 acc
     for name, bk in patterns.items():
-        with tfhe_amd.Context(p6, bk, None) as fast, tfhe_amd.Context(p6, bk, None, generic_kernels=True) as gen:
-            for tv in tvs:
-                a_fast, a_gen = fast.blind_rotate(c, tv), gen.blind_rotate(c, tv)
-                assert np.array_equal(a_fast, a_gen), name
-                assert np.array_equal(a_fast[0], O.blind_rotate(c[0], bk, op, O.SCHOOLBOOK, tv=tv)), name
+        with tfhe_amd.Context(p6, bk, None, generic_kernels=True) as gen:
+            want = [gen.blind_rotate(c, tv) for tv in tvs]
+        for tv, a_gen in zip(tvs, want):
+            assert np.array_equal(a_gen[0], O.blind_rotate(c[0], bk, op, O.SCHOOLBOOK, tv=tv)), name
+        # both forms of the NTT kernels: a batch this small would only take the workgroup-per-gate one
+        for form in ("throughput", "latency"):
+            with tfhe_amd.Context(p6, bk, None, form=form) as fast:
+                assert fast.kernel_family() == "ntt512"
+                for tv, a_gen in zip(tvs, want):
+                    assert np.array_equal(fast.blind_rotate(c, tv), a_gen), (name, form)
 
 
 def test_n2048_ntt_path_vs_generic_and_oracle():
