@@ -649,7 +649,7 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
             asm volatile("" :: "v"(x2[0]), "v"(x2[3]));
 #endif
             LPH_MARK(4)
-            parity_inverse(x2, u, s_rows, tr, lane);  // <= 2.2 p, position 128 k + 2 lane + e
+            parity_inverse(x2, u, s_rows, tr, lane);  // <= 2.21 p, position 128 k + 2 lane + e
 #ifdef TFHE_AMD_LATENCY_CLOCKS
             asm volatile("" :: "v"(x2[0]), "v"(x2[3]));
 #endif

@@ -223,12 +223,12 @@ __host__ __device__ constexpr int pair_slot(int i) { return i + 2 * (i >> 5); }
 constexpr int kPairSlots = 256 + 16;
 
 // Stages 2 .. 9 of the parity-split inverse.  In: layout 4 of i, |x| <= 1.22 p.  Out: layout 1,
-// |x| <= 2.2 p.  Bounds in units of p (a butterfly maps (a, b) to (a + b, 0.5 + 0.75 (a + b) / 5.26);
+// |x| <= 2.21 p.  Bounds in units of p (a butterfly maps (a, b) to (a + b, 0.5 + 0.75 (a + b) / 5.26);
 // a transposition may hand a lane any register's value, so every group starts from the largest bound
 // left): [1.22 x 4] -> near [2.44, .85, 2.44, .85] -> far [4.88, 1.7, 1.2, .74], register 0 reduced
 // -> 1.7 -> near [3.4, .98, ..], registers 0 and 2 reduced -> far [1.0, 1.96, .64, .78] -> 1.96 ->
 // near [3.92, 1.06, ..], reduced -> far [1.0, 2.1, .64, .8] -> 2.1 -> near [4.2, 1.1, ..], reduced ->
-// far [1.0, 2.2, .64, .81].
+// far [1.0, 2.21, .64, .81].  (Recomputed at compile time: half_bounds() at the end of this file.)
 __device__ __forceinline__ void reduce_0_2(double (&x)[4], double p, double pinv) {
     double a[2] = {x[0], x[2]};
     reduce_n<2>(a, p, pinv);
@@ -262,5 +262,65 @@ __device__ __forceinline__ void parity_inverse(double (&x)[4], const NttUniform&
     reduce_0_2(x, p, pinv);
     gs4_far(x, t, p);
 }
+
+// ---- the bounds quoted above, recomputed by the compiler -----------------------------------------------
+// Units of p; kGsTwo53 = 5.26 stands for 2^53 / p (a little below it).  A twiddle product of an operand d
+// leaves 0.5 + 0.75 d / 5.26, a product of two variables (one at most p/2) 0.5 + 1.5 x / 5.26, a
+// reduction 0.5.  `ok` turns false as soon as a sum or a difference of two registers could pass 2^53.
+struct HalfBounds {
+    double forward_out, product, partial, running_sum, inverse_in, inverse_out;
+    bool ok;
+};
+constexpr HalfBounds half_bounds() {
+    HalfBounds r{};
+    r.ok = true;
+    const double eps = kGsEps;
+    auto tw = [&](double d) { r.ok = r.ok && d <= kGsTwo53; return 0.5 + 0.75 * d / kGsTwo53 + eps; };
+    // forward half: stages 0 and 1 stay below 2^46 (0.0001 p); stages 2 .. 8 are butterflies a +- tw(b);
+    // stage 7 (the first of the last group, ct4<true>) reduces its additive inputs
+    double b = 0.0001;
+    for (int stage = 2; stage <= 8; stage++) {
+        const double a = stage == 7 ? 0.5 + eps : b;
+        b = a + tw(b);
+    }
+    r.forward_out = b;
+    r.ok = r.ok && b <= kGsTwo53;
+    r.product = 0.5 + 1.5 * b / kGsTwo53 + eps;
+    r.partial = 2.0 * r.product;  // sum or difference of two partial products
+    // phase 2: six partials, a reduction after every second one
+    r.running_sum = 0.5 + eps + 2.0 * r.partial;
+    r.ok = r.ok && r.running_sum <= kGsTwo53;
+    r.inverse_in = tw(r.running_sum) > 0.5 + eps ? tw(r.running_sum) : 0.5 + eps;  // e = 1: twiddle product; e = 0: reduced
+    // parity_inverse: four groups (near, far) on registers {0, 1, 2, 3}; reductions as in the code
+    double x[4] = {r.inverse_in, r.inverse_in, r.inverse_in, r.inverse_in};
+    for (int g = 0; g < 4; g++) {
+        // near: pairs (0, 1), (2, 3)
+        const double n01 = x[0] + x[1], n23 = x[2] + x[3];
+        x[1] = tw(n01);
+        x[3] = tw(n23);
+        x[0] = n01;
+        x[2] = n23;
+        if (g > 0) x[0] = x[2] = 0.5 + eps;  // reduce_0_2
+        // far: pairs (0, 2), (1, 3)
+        const double f02 = x[0] + x[2], f13 = x[1] + x[3];
+        x[2] = tw(f02);
+        x[3] = tw(f13);
+        x[0] = f02;
+        x[1] = f13;
+        if (g == 0) x[0] = 0.5 + eps;  // the one reduction before the first transposition
+        double top = x[0];
+        for (int k = 1; k < 4; k++) top = x[k] > top ? x[k] : top;
+        if (g < 3)
+            for (int k = 0; k < 4; k++) x[k] = top;  // a transposition may hand a lane any register's value
+        r.inverse_out = top;
+    }
+    r.ok = r.ok && r.inverse_out <= kGsTwo53;
+    return r;
+}
+constexpr HalfBounds kHalfBounds = half_bounds();
+static_assert(kHalfBounds.ok, "a sum in the two-wave transforms of the latency form could pass 2^53");
+static_assert(kHalfBounds.forward_out <= 2.2 && kHalfBounds.product <= 1.13 && kHalfBounds.running_sum <= 5.02 &&
+                  kHalfBounds.inverse_in <= 1.22 && kHalfBounds.inverse_out <= 2.25,
+              "the bounds quoted in the comments of the latency form no longer hold");
 
 }  // namespace tfhe_amd
