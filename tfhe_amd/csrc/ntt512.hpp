@@ -428,6 +428,33 @@ __device__ __forceinline__ void transpose_b_to_a(double (&x)[8], double* tr, int
 // Growth between reductions, in units of p (a CT butterfly maps bound B to
 // B + 0.5 + 0.75 B / 5.26): after the layout-A stages <= 1.72, after layout B <= 4.29,
 // the distance-4 stage reduces its additive inputs, after layout C <= 3.2 < 5.26.
+// The same growth recomputed by the compiler, with the bounds the callers rely on: outputs <= 3.2 p, a
+// product with a key value (<= p/2) <= 1.41 p, three products on top of a reduced accumulator <= 4.74 p.
+struct ForwardBounds {
+    double after_a, after_b, out, product, mac;
+    bool ok;
+};
+constexpr ForwardBounds forward_bounds() {
+    ForwardBounds r{};
+    r.ok = true;
+    auto tw = [&](double d) { r.ok = r.ok && d <= kGsTwo53; return 0.5 + 0.75 * d / kGsTwo53 + kGsEps; };
+    double b = 0.000002;  // inputs up to 2^31 = 1.3e-6 p
+    for (int stage = 1; stage <= 9; stage++) {
+        const double a = stage == 7 ? 0.5 + kGsEps : b;  // ct8<true>: the distance-4 stage reduces its additive inputs
+        b = a + tw(b);
+        if (stage == 3) r.after_a = b;
+        if (stage == 6) r.after_b = b;
+    }
+    r.out = b;
+    r.product = 0.5 + 1.5 * r.out / kGsTwo53 + kGsEps;
+    r.mac = 0.5 + kGsEps + 3.0 * r.product;
+    r.ok = r.ok && r.out <= kGsTwo53 && r.mac <= kGsTwo53;
+    return r;
+}
+constexpr ForwardBounds kForwardBounds = forward_bounds();
+static_assert(kForwardBounds.ok && kForwardBounds.after_a <= 1.73 && kForwardBounds.after_b <= 4.3 &&
+                  kForwardBounds.out <= 3.2 && kForwardBounds.product <= 1.42 && kForwardBounds.mac <= 4.75,
+              "the growth quoted for the forward transform and the multiply-accumulates no longer holds");
 template <bool SMALL, bool FINAL_REDUCE, bool PIN = false>
 __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform& u, const d2* s_tw,
                                                double* tr, int lane) {
