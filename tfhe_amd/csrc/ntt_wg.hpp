@@ -195,6 +195,27 @@ struct WgNtt {
     // Out: last group's layout (position 8t + k, bit-reversed spectrum order), |x| <= 3.2 p.
     // Additive inputs are reduced at the first stage of groups >= 2 (SMALL) or >= 1; the bound
     // then stays below 4.2 p at every stage for LOGN <= 12.
+    // The growth stated above, recomputed by the compiler: largest output bound of forward_many<SMALL>, or -1
+    // if the operand of some twiddle product could pass 2^53.  Group 0 has 3 - SMALL' full butterfly stages
+    // (SMALL = 1 or 2 leave two), a later group reduces the additive inputs of its first stage if it is the
+    // last one, if g >= 2, or if SMALL = 0.
+    static constexpr double forward_bound(int small) {
+        double b = 0.000002;  // inputs up to 2^31
+        bool ok = true;
+        for (int g = 0; g < GROUPS; g++) {
+            const int st = g == 0 ? (small ? 2 : 3) : stages(g);
+            const bool reduce_a = g > 0 && (g == GROUPS - 1 || g >= 2 || small == 0);
+            for (int s = 0; s < st; s++) {
+                ok = ok && b <= kGsTwo53;
+                const double a = (s == 0 && reduce_a) ? 0.5 + kGsEps : b;
+                b = a + 0.5 + 0.75 * b / kGsTwo53 + kGsEps;
+            }
+        }
+        return ok ? b : -1.0;
+    }
+    static_assert(forward_bound(0) >= 0 && forward_bound(0) <= 3.2 && forward_bound(1) >= 0 && forward_bound(1) <= 3.2 &&
+                      forward_bound(2) >= 0 && forward_bound(2) <= 3.2,
+                  "forward_many: outputs above 3.2 p, or an operand above 2^53");
     template <int SMALL, int M, int LDS_LEVEL = 0>
     __device__ static __forceinline__ void forward_many(double (&xs)[M][8], const NttUniform& u,
                                                         const d2* __restrict__ table, double* bufs, int& parity, int t,
