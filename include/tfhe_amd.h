@@ -245,9 +245,14 @@ int tfhe_amd_multi_gate_batch(tfhe_amd_multi_ctx* m, int op, const uint32_t* a, 
                               size_t n_gates);
 int tfhe_amd_multi_bootstrap_batch(tfhe_amd_multi_ctx* m, const uint32_t* c, uint32_t* out, size_t n_gates);
 /* Device-resident form: a[g], b[g], out[g] are arrays of n_gates[g] ciphertexts in the memory of
- * entry g's GPU.  Enqueued on every context's own stream; tfhe_amd_multi_ctx_synchronize waits. */
+ * entry g's GPU.  streams[g] is the stream entry g's share is enqueued on, with the meaning of the
+ * `stream` argument of the single-device calls (NULL = that context's own stream,
+ * TFHE_AMD_DEFAULT_STREAM, or a hipStream_t of entry g's GPU); streams == NULL means every context's
+ * own stream.  A share is ordered only against work on the stream it is given: pass the streams that
+ * produce a[g] and b[g] and consume out[g], or synchronise those before the call and
+ * tfhe_amd_multi_ctx_synchronize (which waits for the contexts' own streams only) after it. */
 int tfhe_amd_multi_nand_batch_device(tfhe_amd_multi_ctx* m, const uint32_t* const* a, const uint32_t* const* b,
-                                     uint32_t* const* out, const size_t* n_gates);
+                                     uint32_t* const* out, const size_t* n_gates, void* const* streams);
 int tfhe_amd_multi_ctx_synchronize(tfhe_amd_multi_ctx* m);
 
 /* Which blind-rotation kernels a context uses:

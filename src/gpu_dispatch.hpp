@@ -142,6 +142,12 @@ struct DeviceKey {
 // is detected only if a sampled word changed: call invalidate() after editing a key.  get() may be
 // called from several threads at once, as the reference's nand() may on one shared EvaluateKey.
 class ContextCache {
+    // The device copy of one key set, built at most once: the first thread to ask for it builds it
+    // under the slot's own mutex while the list stays open to threads that evaluate on other keys.
+    struct Slot {
+        std::mutex mu;
+        std::shared_ptr<DeviceKey> key;  // null until built
+    };
     struct Entry {
         const void* bk_id;
         const void* ks_id;
@@ -149,9 +155,9 @@ class ContextCache {
         tfhe_amd_params params;
         unsigned flags;
         std::vector<int> devs;
-        std::shared_ptr<DeviceKey> key;
+        std::shared_ptr<Slot> slot;
     };
-    std::mutex mutex_;
+    std::mutex mutex_;  // guards entries_ only: lookups, inserts, evictions
     std::list<Entry> entries_;
     static constexpr size_t kMaxEntries = 4;
 
@@ -175,37 +181,55 @@ public:
     }
 
     // `print`: cheap fingerprint of the key contents; `make_bk` / `make_ks`: produce the flat keys
-    // (an empty vector = that key is absent); only called on a miss.  The lock is held while a
-    // missing context is built, so that threads starting together on one key build it once.
+    // (an empty vector = that key is absent); only called on a miss.  Threads that start together on
+    // one key build it once (the others wait on that key's slot); threads on other, cached keys are
+    // not held up by the flattening, upload and transform of a miss.
     template <typename MakeBk, typename MakeKs>
     std::shared_ptr<DeviceKey> get(const tfhe_amd_params& params, const void* bk_id, const void* ks_id, uint64_t print,
                                    MakeBk make_bk, MakeKs make_ks) {
-        std::lock_guard<std::mutex> lock(mutex_);
         const std::vector<int> devs = device_list();
         const unsigned flags = context_flags();
-        for (auto it = entries_.begin(); it != entries_.end(); ++it)
-            if (it->bk_id == bk_id && it->ks_id == ks_id && same(it->params, params) && it->flags == flags &&
-                it->devs == devs) {
-                if (it->print == print) {
-                    entries_.splice(entries_.begin(), entries_, it);
-                    return entries_.front().key;
+        std::shared_ptr<Slot> slot;
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            for (auto it = entries_.begin(); it != entries_.end(); ++it)
+                if (it->bk_id == bk_id && it->ks_id == ks_id && same(it->params, params) && it->flags == flags &&
+                    it->devs == devs) {
+                    if (it->print == print) {
+                        entries_.splice(entries_.begin(), entries_, it);
+                        slot = entries_.front().slot;
+                    } else {
+                        entries_.erase(it);  // same address, different contents
+                    }
+                    break;
                 }
-                entries_.erase(it);  // same address, different contents
-                break;
+            if (!slot) {
+                slot = std::make_shared<Slot>();
+                entries_.push_front(Entry{bk_id, ks_id, print, params, flags, devs, slot});
+                if (entries_.size() > kMaxEntries) entries_.pop_back();
             }
-        const std::vector<uint32_t> bk = make_bk(), ks = make_ks();
-        auto key = std::make_shared<DeviceKey>();
-        if (devs.size() > 1)
-            check(tfhe_amd_multi_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(),
-                                            devs.data(), (int)devs.size(), flags, &key->multi),
-                  "tfhe_amd_multi_ctx_create");
-        else
-            check(tfhe_amd_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(), devs[0],
-                                      flags, &key->single),
-                  "tfhe_amd_ctx_create");
-        entries_.push_front(Entry{bk_id, ks_id, print, params, flags, devs, key});
-        if (entries_.size() > kMaxEntries) entries_.pop_back();
-        return key;
+        }
+        std::lock_guard<std::mutex> build_lock(slot->mu);
+        if (slot->key) return slot->key;
+        try {
+            const std::vector<uint32_t> bk = make_bk(), ks = make_ks();
+            auto key = std::make_shared<DeviceKey>();
+            if (devs.size() > 1)
+                check(tfhe_amd_multi_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(),
+                                                devs.data(), (int)devs.size(), flags, &key->multi),
+                      "tfhe_amd_multi_ctx_create");
+            else
+                check(tfhe_amd_ctx_create(&params, bk.empty() ? nullptr : bk.data(), ks.empty() ? nullptr : ks.data(),
+                                          devs[0], flags, &key->single),
+                      "tfhe_amd_ctx_create");
+            slot->key = key;
+        } catch (...) {
+            // no entry without a context stays behind: the next call starts over
+            std::lock_guard<std::mutex> lock(mutex_);
+            entries_.remove_if([&](const Entry& e) { return e.slot == slot; });
+            throw;
+        }
+        return slot->key;
     }
 };
 

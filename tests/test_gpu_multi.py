@@ -92,6 +92,47 @@ def test_multi_context_device_resident_blocks(keys):
     assert np.array_equal(got, O.Context(p, bk, ks).nand_batch(a, b))
 
 
+def test_multi_context_device_blocks_ordered_on_producer_streams(keys):
+    """The operands are produced by torch kernels on a side stream of every device and consumed
+    there again, with no device-wide synchronisation anywhere: the call is given the producing
+    streams (the default: torch's current stream on every entry's GPU)."""
+    import tfhe_amd
+    import torch
+
+    p, s0, bk, ks = keys
+    devs = _device_list()
+    _, _, a, b = _inputs(p, s0, 3 * len(devs) + 2, seed=23)
+    want = O.Context(p, bk, ks).nand_batch(a, b)
+    with tfhe_amd.MultiContext(tfhe_amd.params_default(), bk, ks, devs) as m:
+        side = {d: torch.cuda.Stream(device=d) for d in set(devs)}
+        host, ta, tb, to, neg = [], [], [], [], []
+        for i, d in enumerate(devs):
+            lo, hi = m.shard(a.shape[0], i)
+            # pinned host copies: the uploads below are really asynchronous
+            host.append((torch.from_numpy((0 - a[lo:hi]).view(np.int32)).pin_memory(),
+                         torch.from_numpy((b[lo:hi] ^ np.uint32(0x5a5a5a5a)).view(np.int32)).pin_memory()))
+        for rep in range(2):   # the second round reuses the workspaces the first one left in flight
+            ta, tb, to, neg = [], [], [], []
+            for i, d in enumerate(devs):
+                with torch.cuda.stream(side[d]):
+                    big = torch.empty((1 << 22,), dtype=torch.int32, device=f"cuda:{d}")
+                    for _ in range(8):   # keeps the stream busy while the host runs ahead
+                        big.add_(1)
+                    na = host[i][0].to(f"cuda:{d}", non_blocking=True)
+                    xb = host[i][1].to(f"cuda:{d}", non_blocking=True)
+                    ta.append(0 - na)              # a, produced by a torch kernel on the side stream
+                    tb.append(xb ^ 0x5a5a5a5a)     # b likewise
+                    to.append(torch.empty_like(ta[-1]))
+            m.nand_device(ta, tb, to, streams=[side[d] for d in devs])
+            for i, d in enumerate(devs):
+                with torch.cuda.stream(side[d]):
+                    neg.append(0 - to[i])          # consumed on the same stream, no synchronisation in between
+            for s in side.values():
+                s.synchronize()
+            got = np.concatenate([(0 - t).cpu().numpy().view(np.uint32) for t in neg])
+            assert np.array_equal(got, want), f"round {rep}"
+
+
 def test_eight_host_threads_share_one_context(keys):
     """Concurrent calls on ONE context from eight host threads (ctypes releases the GIL): batches of
     different sizes, host-pointer and device-pointer entry points mixed, every word as the oracle's."""

@@ -122,7 +122,8 @@ def library():
     lib.tfhe_amd_multi_nand_batch.argtypes = [vp, vp, vp, vp, sz]
     lib.tfhe_amd_multi_gate_batch.argtypes = [vp, i32, vp, vp, vp, sz]
     lib.tfhe_amd_multi_bootstrap_batch.argtypes = [vp, vp, vp, sz]
-    lib.tfhe_amd_multi_nand_batch_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]
+    lib.tfhe_amd_multi_nand_batch_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
+                                                     C.POINTER(vp)]
     lib.tfhe_amd_multi_ctx_synchronize.argtypes = [vp]
     lib.tfhe_amd_ctx_kernel_family.argtypes = [vp]
     lib.tfhe_amd_ctx_kernel_family.restype = C.c_char_p
@@ -525,9 +526,14 @@ class MultiContext:
                                                         out.ctypes.data_as(C.c_void_p), c.shape[0]))
         return out
 
-    def nand_device(self, a, b, out):
+    OWN_STREAMS = "own"
+
+    def nand_device(self, a, b, out, streams=None):
         """a, b, out: one GPU tensor [G_g, n+1] per entry of the device list, each on that entry's
-        GPU.  Asynchronous on every context's own stream; synchronize() waits for all."""
+        GPU.  Asynchronous.  streams: None = torch's current stream on every entry's GPU, so that
+        each share is ordered behind whatever produced its tensors and ahead of later torch work on
+        them; MultiContext.OWN_STREAMS = every context's own stream (the caller orders producers
+        and consumers; synchronize() waits); or one torch stream per entry."""
         n = len(self.devices)
         if not (len(a) == len(b) == len(out) == n):
             raise ValueError("one tensor per device expected")
@@ -537,11 +543,30 @@ class MultiContext:
         pa = VP(*[_dev_ptr(t, wi).value or 0 for t, wi in zip(a, w)])
         pb = VP(*[_dev_ptr(t, wi).value or 0 for t, wi in zip(b, w)])
         po = VP(*[_dev_ptr(t, wi).value or 0 for t, wi in zip(out, w)])
-        _check(library().tfhe_amd_multi_nand_batch_device(self._h, pa, pb, po, SZ(*g)))
+        if streams == self.OWN_STREAMS:
+            ps = None
+        else:
+            import torch
+
+            if streams is None:
+                streams = [torch.cuda.current_stream(d) for d in self.devices]
+            if len(streams) != n:
+                raise ValueError("one stream per device expected")
+            # the default stream's handle is 0, which the C ABI spells TFHE_AMD_DEFAULT_STREAM = (void*)-1
+            ps = VP(*[(s.cuda_stream or C.c_void_p(-1).value) for s in streams])
+        _check(library().tfhe_amd_multi_nand_batch_device(self._h, pa, pb, po, SZ(*g), ps))
         return out
 
     def synchronize(self):
+        """Waits for every context's own stream and, when torch is loaded, for torch's current
+        stream on every entry's GPU (where nand_device goes by default)."""
         _check(library().tfhe_amd_multi_ctx_synchronize(self._h))
+        import sys
+
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            for d in set(self.devices):
+                torch.cuda.current_stream(d).synchronize()
 
 
 def seed_words(seed):

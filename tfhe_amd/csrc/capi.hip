@@ -1349,12 +1349,12 @@ int tfhe_amd_multi_bootstrap_batch(tfhe_amd_multi_ctx* m, const uint32_t* c, uin
 }
 
 int tfhe_amd_multi_nand_batch_device(tfhe_amd_multi_ctx* m, const uint32_t* const* a, const uint32_t* const* b,
-                                     uint32_t* const* out, const size_t* n_gates) {
+                                     uint32_t* const* out, const size_t* n_gates, void* const* streams) {
     if (!m) return fail(TFHE_AMD_ERR_ARGUMENT, "null context");
     if (!a || !b || !out || !n_gates) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
     // enqueueing is quick: one host thread walks the devices, the GPUs run side by side
     for (size_t g = 0; g < m->ctx.size(); g++) {
-        const int rc = tfhe_amd_nand_batch_device(m->ctx[g], a[g], b[g], out[g], n_gates[g], nullptr);
+        const int rc = tfhe_amd_nand_batch_device(m->ctx[g], a[g], b[g], out[g], n_gates[g], streams ? streams[g] : nullptr);
         if (rc) return rc;
     }
     return TFHE_AMD_OK;
