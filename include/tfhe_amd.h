@@ -135,8 +135,12 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
  * inputs and the lv1 ciphertexts, (n+1) + (N*K+1) words per gate) is a static device array of
  * TFHE_AMD_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
  * Batches whose workspace exceeds it (more than 2,523 gates at the default parameters) are rejected
- * with TFHE_AMD_ERR_ARGUMENT.  All contexts on one GPU share that GPU's array: calls that overlap
- * in time on one GPU race, whatever their contexts or streams; the caller orders them.  Kernel
+ * with TFHE_AMD_ERR_ARGUMENT.  All contexts on one GPU share that GPU's array, which keeps the last
+ * call's contents.  Calls through this entry point on one GPU are ordered one behind the other even
+ * on different streams (an event created with the first context on that GPU: recording it and
+ * waiting for it allocate nothing).  Two cases stay with the caller: a call on a stream under
+ * capture records no such ordering into the graph, so launches of that graph must not overlap other
+ * users of the array on the same GPU; and callers in different processes share nothing.  Kernel
  * timing (tfhe_amd_ctx_enable_timing) does not record these calls. */
 #define TFHE_AMD_NOALLOC_SCRATCH_BYTES ((size_t)16 << 20)
 int tfhe_amd_nand_batch_device_noalloc(tfhe_amd_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out,

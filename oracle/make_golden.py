@@ -21,10 +21,13 @@ GOLDEN = HERE.parent / "tests" / "golden"
 
 
 def main() -> int:
+    """make_golden.py            regenerate every family
+    make_golden.py kswide     only the wide-base key-switch family (tests/golden/kswide.npz)"""
+    only = sys.argv[1:2]
     subprocess.run(["make", "-C", str(HERE), "ref"], check=True)
     GOLDEN.mkdir(parents=True, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.run([str(HERE / "_ref" / "ref_golden"), tmp], check=True)
+        subprocess.run([str(HERE / "_ref" / "ref_golden"), tmp] + only, check=True)
         groups = {}
         for f in sorted(pathlib.Path(tmp).glob("*.npy")):
             family, _, field = f.stem.partition("_")

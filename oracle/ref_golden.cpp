@@ -388,9 +388,25 @@ PARAM_TLWE(KS1b, 48, 2.9802322387695312e-08);
 PARAM_KS(KS8, 8, 2);
 PARAM_KS(KS3x3, 3, 3);
 
+PARAM_TLWE(KS1c, 24, 2.9802322387695312e-08);
+PARAM_TLWE(KS1d, 12, 2.9802322387695312e-08);
+PARAM_KS(KS4x4, 4, 4);
+PARAM_KS(KS6x5, 6, 5);
+PARAM_KS(KS3x7, 3, 7);
+PARAM_KS(KS1x8, 1, 8);
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s <out_dir>\n", argv[0]); return 1; }
+    if (argc < 2) { fprintf(stderr, "usage: %s <out_dir> [family]\n", argv[0]); return 1; }
     g_dir = argv[1];
+    if (argc > 2 && std::string(argv[2]) == "kswide") {
+        // identity key switch at the wider bases the reference accepts (T * BASE_BIT <= 31), a family of
+        // its own so that it can be added without regenerating the others
+        gen_key_switch<KS0, KS1c, KS4x4>("kswide_t4b4", 8);
+        gen_key_switch<KS0, KS1c, KS6x5>("kswide_t6b5", 8);
+        gen_key_switch<KS0, KS1d, KS3x7>("kswide_t3b7", 8);
+        gen_key_switch<KS0, KS1d, KS1x8>("kswide_t1b8", 8);
+        return 0;
+    }
     gen_pipeline<A0, AR, A1, AG, AK>("toyA", 64, 4);
     gen_pipeline<B0, BR, B1, BG_, BK_>("toyB", 64, 4);
     gen_pipeline<C0, CR, C1, CG, CK>("toyC", 32, 2);

@@ -40,7 +40,7 @@ int tfo_params_valid(const tfo_params* p) {
     if (p->N < 2 || (p->N & (p->N - 1))) return 0;                 /* reference src/trgsw.hpp:142-143 */
     if (p->bg_bit != 8 && p->bg_bit != 16) return 0;               /* reference src/types.hpp:11-19  */
     if (p->L * p->bg_bit > 31 || p->T * p->base_bit > 31) return 0; /* reference src/trgsw.hpp:28-29 */
-    if (p->base_bit < 1 || p->base_bit > 8) return 0;
+    if (p->base_bit < 1) return 0;                                  /* reference src/tlwe_key_switching.hpp:52-53 */
     return 1;
 }
 

@@ -46,6 +46,23 @@ def test_params_and_sizes():
     assert tfhe_amd.version().count(".") == 2
 
 
+def test_every_parameter_set_the_reference_accepts_is_supported():
+    """The reference's constraints are static_asserts and shift widths: a power-of-two ring
+    (src/trgsw.hpp:142-143), BG_BIT in {8, 16, 32} with L * BG_BIT <= 31 (src/types.hpp:11-19,
+    src/trgsw.hpp:28-29), T * BASE_BIT <= 31 (src/tlwe_key_switching.hpp:52-53).  Every such set has
+    kernels; everything else is an argument error."""
+    lib = tfhe_amd.library()
+    for N in (2, 16, 512, 1024, 2048, 4096, 8192, 1 << 16):
+        for K in (1, 2, 3, 5):
+            for bg, L in ((8, 1), (8, 2), (8, 3), (16, 1)):
+                for T, bb in ((5, 2), (8, 2), (10, 3), (7, 4), (6, 5), (3, 7), (3, 10), (1, 16), (1, 31), (31, 1)):
+                    p = tfhe_amd.Params(7, N, K, bg, L, T, bb)
+                    assert lib.tfhe_amd_params_supported(C.byref(p)) == 0, (N, K, bg, L, T, bb)
+    for bad in ((7, 512, 1, 8, 2, 8, 4), (7, 512, 1, 16, 2, 5, 2), (7, 512, 1, 32, 1, 5, 2), (7, 768, 1, 8, 2, 5, 2),
+                (0, 512, 1, 8, 2, 5, 2), (7, 512, 0, 8, 2, 5, 2), (7, 512, 1, 8, 2, 0, 2), (7, 512, 1, 8, 2, 5, 0)):
+        assert lib.tfhe_amd_params_supported(C.byref(tfhe_amd.Params(*bad))) == 1, bad
+
+
 def test_argument_errors_without_gpu():
     lib = tfhe_amd.library()
     p = tfhe_amd.params_default()

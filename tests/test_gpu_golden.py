@@ -43,12 +43,14 @@ def test_nand_pipeline_vs_reference(golden, name):
         assert np.array_equal(ctx.nand(g["a"], g["b"]), g["out"])
 
 
-@pytest.mark.parametrize("tag", ["t5", "t8", "t3b3"])
+@pytest.mark.parametrize("tag", ["t5", "t8", "t3b3", "wide:t4b4", "wide:t6b5", "wide:t3b7", "wide:t1b8"])
 def test_identity_key_switch_vs_reference(golden, tag):
-    # reference src/tlwe_key_switching.hpp:47-65; context with a key-switching key only
+    # reference src/tlwe_key_switching.hpp:47-65; context with a key-switching key only.  "wide": BASE_BIT 4 .. 8
+    # (the gather kernel; the others run on the tiled kernel)
     import tfhe_amd
 
-    g = golden("ks")
+    g = golden("kswide" if tag.startswith("wide:") else "ks")
+    tag = tag.split(":")[-1]
     n, nlv1, _, _, _, T, bb = [int(v) for v in g[f"{tag}_params"]]
     N = nlv1 & -nlv1  # the key switch only sees N*K = nlv1; pick a power-of-two N dividing it
     p = tfhe_amd.Params(n, N, nlv1 // N, 8, 1, T, bb)
@@ -338,7 +340,27 @@ def _random_parameter_sets(count, seed):
     return sets
 
 
-@pytest.mark.parametrize("shape", _random_parameter_sets(24, seed=2024))
+def _wide_parameter_sets(count, seed):
+    """The corners the draw above leaves out: key-switch bases of 4 .. 6 bits (table size allowing) and
+    rings of 2048 .. 8192 (small n, K = 1 .. 2: the O(N^2) oracle takes seconds there)."""
+    rs = np.random.RandomState(seed)
+    sets = []
+    while len(sets) < count:
+        big_ring = len(sets) % 2 == 1
+        N = 1 << (rs.randint(11, 14) if big_ring else rs.randint(3, 10))
+        K = int(rs.randint(1, 3))
+        bg = int(rs.choice([8, 16]))
+        L = 1 if bg == 16 else int(rs.randint(1, 4))
+        bb = int(rs.randint(1, 4) if big_ring else rs.randint(4, 7))
+        T = int(rs.randint(1, min(31 // bb, 6) + 1))
+        n = int(rs.randint(1, 4) if big_ring else rs.randint(1, 13))
+        if N * K * T * (1 << bb) * (n + 1) > (1 << 24) or (big_ring and N * K * L > 16384):
+            continue
+        sets.append((n, int(N), K, bg, L, T, bb))
+    return sets
+
+
+@pytest.mark.parametrize("shape", _random_parameter_sets(24, seed=2024) + _wide_parameter_sets(10, seed=2025))
 def test_random_parameter_sets_vs_oracle(shape):
     """The whole gate (reference src/hom_nand.hpp:74-81) at parameter sets nobody picked by hand: the kernels
     chosen by the library for each set (NTT where one exists, the exact O(N^2) ones elsewhere) against the

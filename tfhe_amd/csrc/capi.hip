@@ -73,20 +73,35 @@ constexpr size_t kNoAllocWords = TFHE_AMD_NOALLOC_SCRATCH_BYTES / sizeof(uint32_
 __device__ __align__(256) uint32_t scratch[kNoAllocWords];
 
 constexpr int kMaxDevices = 64;
+// Per-device state of the static workspace: its address on that device, and the event and stream of
+// the last call that used it, so that calls on different streams run one behind the other.
+struct ScratchState {
+    uint32_t* ptr = nullptr;
+    hipEvent_t done = nullptr;    // recorded behind the last kernel that touches the workspace
+    hipStream_t last = nullptr;   // stream of that call
+    bool used = false;
+    std::mutex mu;                // one call at a time enqueues on a device
+};
+ScratchState g_scratch[kMaxDevices];
 std::mutex g_scratch_mutex;
-uint32_t* g_scratch_ptr[kMaxDevices] = {};
 
-// Address of `scratch` on GPU `device`, which must be the current device.  Resolved once per device.
-hipError_t scratch_of(int device, uint32_t** out) {
+// State of `scratch` on GPU `device`, which must be the current device.  The address and the event
+// are resolved once per device (when the first context on it is created: no allocation later).
+hipError_t scratch_of(int device, ScratchState** out) {
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (!g_scratch_ptr[device]) {
+    ScratchState& st = g_scratch[device];
+    if (!st.ptr) {
         void* ptr = nullptr;
-        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
-        g_scratch_ptr[device] = static_cast<uint32_t*>(ptr);
+        if (!st.done) {
+            e = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        st.ptr = static_cast<uint32_t*>(ptr);
     }
-    *out = g_scratch_ptr[device];
+    *out = &st;
     return hipSuccess;
 }
 
@@ -139,7 +154,7 @@ struct tfhe_amd_ctx {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<Lane*> lanes;
-    uint32_t* d_scratch = nullptr;  // this device's copy of the static no-allocation workspace
+    ScratchState* scratch = nullptr;  // this device's copy of the static no-allocation workspace
     std::mutex timing_mu;
     // timing
     std::atomic<bool> timing{false};
@@ -370,21 +385,32 @@ void lane_free(Lane* lane) {
 }
 
 // Exclusive use of one lane of a context until the lease goes out of scope.  The context's device
-// must be current.  Prefers a free lane whose workspace was last used on `prefer` (no cross-stream
-// wait needed), then any free lane, then a new one; with kMaxLanes lanes all busy it waits.
+// must be current.  `prefer`: the stream the call enqueues on; `own_stream`: the call runs on the
+// lane's private stream (host-pointer calls).  Order of choice: a free lane whose workspace was last
+// used on the call's stream (no cross-stream wait needed); a free lane whose last user has finished
+// (or that was never used); a new lane while fewer than kMaxLanes exist, so that calls on different
+// streams do not queue behind each other's workspace; any free lane; with all lanes busy it waits.
 struct LaneLease {
     tfhe_amd_ctx* ctx;
     Lane* lane = nullptr;
     int rc = TFHE_AMD_OK;
-    LaneLease(tfhe_amd_ctx* c, hipStream_t prefer) : ctx(c) {
+    LaneLease(tfhe_amd_ctx* c, hipStream_t prefer, bool own_stream = false) : ctx(c) {
         std::unique_lock<std::mutex> lock(ctx->mu);
         for (;;) {
             Lane* free_lane = nullptr;
+            Lane* idle_lane = nullptr;
+            Lane* same_lane = nullptr;
             for (Lane* l : ctx->lanes) {
                 if (l->busy) continue;
-                if (!free_lane || (l->ws_used && l->ws_stream == prefer)) free_lane = l;
-                if (l->ws_used && l->ws_stream == prefer) break;
+                if (!free_lane) free_lane = l;
+                const hipStream_t want = own_stream ? l->stream : prefer;
+                if (l->ws_used && l->ws_stream == want) { same_lane = l; break; }
+                if (!idle_lane && (!l->ws_used || hipEventQuery(l->ws_done) == hipSuccess)) idle_lane = l;
             }
+            (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error
+            if (same_lane) free_lane = same_lane;
+            else if (idle_lane) free_lane = idle_lane;
+            else if ((int)ctx->lanes.size() < kMaxLanes) free_lane = nullptr;
             if (free_lane) { lane = free_lane; break; }
             if ((int)ctx->lanes.size() < kMaxLanes) {
                 Lane* l = new (std::nothrow) Lane();
@@ -465,9 +491,17 @@ int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, u
     else if (ctx->wg)
         HIP_TRY(launch_blind_rotate_wg(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit,
                                        ctx->shift, ctx->pack_shift, ctx->pack, extract, s));
-    else
-        HIP_TRY(launch_blind_rotate_generic(ctx->d_bk_raw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit, extract,
-                                            s));
+    else {
+        // rings beyond LDS keep their per-gate state in a workspace that lives for this launch
+        // (stream-ordered allocation: no host synchronisation)
+        const size_t ws_words = generic_big_workspace_words(n_gates, p.N, p.K, p.L);
+        void* ws = nullptr;
+        if (ws_words) HIP_TRY(hipMallocAsync(&ws, ws_words * sizeof(uint32_t), s));
+        const hipError_t e = launch_blind_rotate_generic(ctx->d_bk_raw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit,
+                                                         extract, static_cast<uint32_t*>(ws), s);
+        if (ws) (void)hipFreeAsync(ws, s);
+        HIP_TRY(e);
+    }
     return TFHE_AMD_OK;
 }
 
@@ -533,7 +567,7 @@ int with_staging(tfhe_amd_ctx* ctx, const uint32_t* const* in, const size_t* in_
                  size_t out_words, Body body) {
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(TFHE_AMD_ERR_HIP, "hipSetDevice failed");
-    LaneLease lease(ctx, nullptr);
+    LaneLease lease(ctx, nullptr, true);
     if (lease.rc) return lease.rc;
     Lane* lane = lease.lane;
     size_t total = out_words;
@@ -541,6 +575,13 @@ int with_staging(tfhe_amd_ctx* ctx, const uint32_t* const* in, const size_t* in_
     int rc = ensure_io(lane, total);
     if (rc) return rc;
     const uint32_t* dev_in[4] = {nullptr, nullptr, nullptr, nullptr};
+    // On failure nothing may stay in flight on the lane's stream: the copies read and write the
+    // caller's host arrays, and the lane goes back to the pool.
+    struct Drain {
+        hipStream_t s;
+        bool armed = true;
+        ~Drain() { if (armed) (void)hipStreamSynchronize(s); }
+    } drain{lane->stream};
     uint32_t* cur = lane->d_io;
     for (int k = 0; k < n_in; k++) {
         if (in[k]) {
@@ -553,6 +594,7 @@ int with_staging(tfhe_amd_ctx* ctx, const uint32_t* const* in, const size_t* in_
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out, cur, out_words * sizeof(uint32_t), hipMemcpyDeviceToHost, lane->stream));
     HIP_TRY(hipStreamSynchronize(lane->stream));
+    drain.armed = false;
     return TFHE_AMD_OK;
 }
 
@@ -636,7 +678,7 @@ int external_product_common(const tfhe_amd_params* p, const uint32_t* trgsw, con
     const bool wg = !fast && wg_has_kernel(p->N, p->K, p->L, p->bg_bit) &&
                     wg_split(p->N, p->K, p->L, p->bg_bit, &tiles, &shift, &pack_shift, &pack);
     if (!fast && !wg && !generic_has_kernel(p->N, p->K, p->L))
-        return fail(TFHE_AMD_ERR_UNSUPPORTED, "ring too large for the generic kernel");
+        return fail(TFHE_AMD_ERR_UNSUPPORTED, "ring degree beyond 2^26");
     if (batch && (!trgsw || !x0 || !out || (mode && !x1))) return fail(TFHE_AMD_ERR_ARGUMENT, "null array argument");
     if (batch == 0) return TFHE_AMD_OK;
     if (batch > (size_t)1 << 24) return fail(TFHE_AMD_ERR_ARGUMENT, "batch too large");
@@ -689,7 +731,13 @@ int external_product_common(const tfhe_amd_params* p, const uint32_t* trgsw, con
                                                p->L, p->bg_bit, shift, pack_shift, pack, mode, sc.stream));
         }
     } else {
-        HIP_TRY(launch_external_product_generic(d_g, d_0, d_1, d_out, batch, p->N, p->K, p->L, p->bg_bit, mode, sc.stream));
+        const size_t ws_words = generic_big_workspace_words(batch, p->N, p->K, p->L);
+        void* ws = nullptr;
+        if (ws_words) HIP_TRY(hipMallocAsync(&ws, ws_words * sizeof(uint32_t), sc.stream));
+        const hipError_t e = launch_external_product_generic(d_g, d_0, d_1, d_out, batch, p->N, p->K, p->L, p->bg_bit, mode,
+                                                             static_cast<uint32_t*>(ws), sc.stream);
+        if (ws) (void)hipFreeAsync(ws, sc.stream);
+        HIP_TRY(e);
     }
     HIP_TRY(hipMemcpyAsync(out, d_out, batch * W * 4, hipMemcpyDeviceToHost, sc.stream));
     HIP_TRY(hipStreamSynchronize(sc.stream));
@@ -761,7 +809,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params* p, const uint32_t* bk, const uint
     } while (0)
 
     CTX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    CTX_TRY(scratch_of(device, &ctx->d_scratch));
+    CTX_TRY(scratch_of(device, &ctx->scratch));
     const size_t bk_words = tfhe_amd_bk_words(p), ks_words = tfhe_amd_ks_words(p);
     const int n1 = p->n + 1, nlv1 = p->N * p->K;
     DevBuf up_bk, up_ks;  // upload scratch for host-resident keys
@@ -952,13 +1000,31 @@ int tfhe_amd_nand_batch_device_noalloc(tfhe_amd_ctx* ctx, const uint32_t* a, con
         return fail(TFHE_AMD_ERR_ARGUMENT, "batch of " + std::to_string(n_gates) + " gates exceeds the static workspace (" +
                                                std::to_string(kNoAllocWords / per_gate) +
                                                " gates at this parameter set); use tfhe_amd_nand_batch_device");
-    if (!ctx->d_scratch) return fail(TFHE_AMD_ERR_HIP, "static workspace unresolved on this device");
+    if (!ctx->scratch || !ctx->scratch->ptr) return fail(TFHE_AMD_ERR_HIP, "static workspace unresolved on this device");
     DeviceGuard guard(ctx->device);
     hipStream_t s = pick_stream(ctx, stream);
-    uint32_t* const d_c = ctx->d_scratch;
-    uint32_t* const d_lv1 = ctx->d_scratch + n_gates * n1;
+    ScratchState& st = *ctx->scratch;
+    std::lock_guard<std::mutex> lock(st.mu);
+    // A stream under capture records a graph: an event from outside the capture may not enter it, and
+    // the graph's launches are ordered by the streams the caller launches them on.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capture) != hipSuccess) {
+        (void)hipGetLastError();
+        capture = hipStreamCaptureStatusNone;
+    }
+    const bool capturing = capture != hipStreamCaptureStatusNone;
+    if (!capturing && st.used && st.last != s) HIP_TRY(hipStreamWaitEvent(s, st.done, 0));
+    uint32_t* const d_c = st.ptr;
+    uint32_t* const d_lv1 = st.ptr + n_gates * n1;
     HIP_TRY(launch_nand_combine(d_c, a, b, n_gates, (int)n1, s));
-    return run_bootstrap(ctx, nullptr, d_c, out, n_gates, s, 0, d_lv1);
+    rc = run_bootstrap(ctx, nullptr, d_c, out, n_gates, s, 0, d_lv1);
+    if (rc) return rc;
+    if (!capturing) {
+        HIP_TRY(hipEventRecord(st.done, s));
+        st.last = s;
+        st.used = true;
+    }
+    return TFHE_AMD_OK;
 }
 
 int tfhe_amd_gate_batch_device(tfhe_amd_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, uint32_t* out,

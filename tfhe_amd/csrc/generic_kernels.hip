@@ -1,4 +1,5 @@
-// Parameter-generic kernels: any ring degree N (power of two, <= 2048), any K, L, gadget base.
+// Parameter-generic kernels: any ring degree N (power of two), any K, L, gadget base.  Two forms: per-gate
+// state in LDS (N <= 2048 and (2 (K+1) + 1 + (K+1) L) N words within 160 KB), or in a global workspace.
 // They evaluate the negacyclic products directly in wrap-around 32-bit arithmetic, which is
 // the definition itself (what the reference executes for N < 32, src/types.hpp:225-236), so
 // they are exact for every parameter set at O(N^2) cost.  They back the lower-level entry
@@ -155,19 +156,158 @@ blind_rotate_generic_kernel(const uint32_t* __restrict__ bk, const uint32_t* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same algorithm for rings whose per-gate state does not fit LDS (N > 2048, or many mask
+// polynomials / levels): accumulator, difference and digits live in a global workspace of
+// generic_big_workspace_words() words per item; one workgroup of 1024 threads per item.  A product
+// stages one digit polynomial and one key polynomial in LDS while both fit (N <= 16384) and reads
+// them from global memory beyond that.
+// ------------------------------------------------------------------------------------------
+constexpr int kBigThreads = 1024;
+constexpr int kBigLdsN = 16384;  // 2 x 64 KB
+
+__device__ void decompose_big(int32_t* dig, const uint32_t* src, const GenShape& s) {
+    const uint32_t off = decomp_offset(s.L, s.bg), mask = (1u << s.bg) - 1;
+    const int half = 1 << (s.bg - 1);
+    for (int e = threadIdx.x; e < s.K1 * s.N; e += kBigThreads) {
+        const int q = e / s.N, j = e - q * s.N;
+        const uint32_t t = src[e] + off;
+        for (int l = 0; l < s.L; l++)
+            dig[(size_t)(q * s.L + l) * s.N + j] = (int)((t >> (32 - s.bg * (l + 1))) & mask) - half;
+    }
+    __syncthreads();
+}
+
+// res_col += sum_r dig_r (*) C[r][col]; dig [R][N] and res [K1][N] in global memory, lds: 2 N words or null
+__device__ void extprod_big(uint32_t* res, const int32_t* dig, const uint32_t* __restrict__ C, uint32_t* lds,
+                            const GenShape& s) {
+    const int N = s.N;
+    for (int col = 0; col < s.K1; col++)
+        for (int r = 0; r < s.R; r++) {
+            const uint32_t* poly = C + ((size_t)r * s.K1 + col) * N;
+            const int32_t* d = dig + (size_t)r * N;
+            if (lds) {
+                __syncthreads();
+                for (int j = threadIdx.x; j < N; j += kBigThreads) {
+                    lds[j] = poly[j];
+                    lds[N + j] = (uint32_t)d[j];
+                }
+                __syncthreads();
+                poly = lds;
+                d = reinterpret_cast<const int32_t*>(lds + N);
+            }
+            for (int k = threadIdx.x; k < N; k += kBigThreads) {
+                uint32_t sum = 0u;
+                for (int j = 0; j <= k; j++) sum += poly[k - j] * (uint32_t)d[j];
+                for (int j = k + 1; j < N; j++) sum -= poly[k - j + N] * (uint32_t)d[j];
+                res[(size_t)col * N + k] += sum;
+            }
+        }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kBigThreads)
+external_product_generic_big_kernel(const uint32_t* __restrict__ trgsw, const uint32_t* __restrict__ x0,
+                                    const uint32_t* __restrict__ x1, uint32_t* __restrict__ out, uint32_t* __restrict__ ws,
+                                    GenShape s, int mode, int use_lds) {
+    extern __shared__ uint32_t s_mem[];
+    const int W = s.K1 * s.N;
+    const size_t item = blockIdx.x;
+    uint32_t* in = ws + item * (size_t)(2 * W + s.R * s.N);
+    uint32_t* res = out + item * (size_t)W;
+    int32_t* dig = reinterpret_cast<int32_t*>(in + 2 * W);
+    for (int e = threadIdx.x; e < W; e += kBigThreads) {
+        const uint32_t a = x0[item * W + e];
+        in[e] = mode ? x1[item * W + e] - a : a;
+        res[e] = mode ? a : 0u;
+    }
+    __syncthreads();
+    decompose_big(dig, in, s);
+    extprod_big(res, dig, trgsw + item * (size_t)s.R * W, use_lds ? s_mem : nullptr, s);
+}
+
+__global__ void __launch_bounds__(kBigThreads)
+blind_rotate_generic_big_kernel(const uint32_t* __restrict__ bk, const uint32_t* __restrict__ c,
+                                const uint32_t* __restrict__ tv, uint32_t* __restrict__ out, uint32_t* __restrict__ ws,
+                                GenShape s, int n, int extract, int use_lds) {
+    extern __shared__ uint32_t s_mem[];
+    const int N = s.N, W = s.K1 * N;
+    const size_t gate = blockIdx.x;
+    uint32_t* acc = ws + gate * (size_t)(2 * W + s.R * N);
+    uint32_t* diff = acc + W;
+    int32_t* dig = reinterpret_cast<int32_t*>(diff + W);
+    const uint32_t* cg = c + gate * (size_t)(n + 1);
+    int log2n = 0;
+    while ((1 << log2n) < N) log2n++;
+    const int sh = 32 - (log2n + 1);
+    const int bbar = (int)(cg[0] >> sh);
+    for (int e = threadIdx.x; e < W; e += kBigThreads) {
+        const int q = e / N, j = e - q * N;
+        const int src = (j + bbar) & (2 * N - 1);
+        const uint32_t v = tv ? tv[q * N + (src & (N - 1))] : (q == 0 ? (1u << 29) : 0u);
+        acc[e] = (src & N) ? 0u - v : v;
+    }
+    __syncthreads();
+    for (int i = 0; i < n; i++) {
+        const int abar = (int)((cg[1 + i] + (1u << (sh - 1))) >> sh);
+        for (int e = threadIdx.x; e < W; e += kBigThreads) {
+            const int q = e / N, j = e - q * N;
+            const int src = (j - abar) & (2 * N - 1);
+            const uint32_t v = acc[q * N + (src & (N - 1))];
+            diff[e] = ((src & N) ? 0u - v : v) - acc[e];
+        }
+        __syncthreads();
+        decompose_big(dig, diff, s);
+        extprod_big(acc, dig, bk + (size_t)i * s.R * W, use_lds ? s_mem : nullptr, s);
+    }
+    if (extract) {
+        uint32_t* o = out + gate * (size_t)((s.K1 - 1) * N + 1);
+        for (int e = threadIdx.x; e < (s.K1 - 1) * N; e += kBigThreads) {
+            const int q = e / N, j = e - q * N;
+            const uint32_t v = acc[(1 + q) * N + j];
+            if (j == 0) o[1 + q * N] = v;
+            else        o[1 + q * N + (N - j)] = 0u - v;
+        }
+        if (threadIdx.x == 0) o[0] = acc[0];
+    } else {
+        for (int e = threadIdx.x; e < W; e += kBigThreads) out[gate * (size_t)W + e] = acc[e];
+    }
+}
+
 static size_t generic_lds_bytes(int N, int K1, int R) { return sizeof(uint32_t) * ((size_t)2 * K1 * N + N + (size_t)R * N); }
 
+static bool generic_fits_lds(int N, int K, int L) {
+    return N <= kGenThreads * kGenMaxOut && generic_lds_bytes(N, K + 1, (K + 1) * L) <= 160 * 1024;
+}
+
+// every ring the reference accepts (a power of two, src/trgsw.hpp:142-143) with any K and L; rings
+// above 2^26 would overflow the 32-bit indices of these kernels
 bool generic_has_kernel(int N, int K, int L) {
-    if (N < 2 || N > kGenThreads * kGenMaxOut || (N & (N - 1))) return false;
-    return generic_lds_bytes(N, K + 1, (K + 1) * L) <= 160 * 1024;
+    return N >= 2 && N <= (1 << 26) && !(N & (N - 1)) && K >= 1 && L >= 1;
+}
+
+size_t generic_big_workspace_words(size_t items, int N, int K, int L) {
+    if (generic_fits_lds(N, K, L)) return 0;
+    return items * ((size_t)2 * (K + 1) * N + (size_t)(K + 1) * L * N);
 }
 
 hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
                                            uint32_t* out, size_t batch, int N, int K, int L, int bg, int mode,
-                                           hipStream_t stream) {
+                                           uint32_t* ws, hipStream_t stream) {
     if (batch == 0) return hipSuccess;
     if (!generic_has_kernel(N, K, L)) return hipErrorInvalidValue;
     GenShape s{N, K + 1, L, (K + 1) * L, bg};
+    if (!generic_fits_lds(N, K, L)) {
+        if (!ws) return hipErrorInvalidValue;
+        const int use_lds = N <= kBigLdsN;
+        const size_t big_lds = use_lds ? sizeof(uint32_t) * 2 * (size_t)N : 0;
+        hipError_t e = hipFuncSetAttribute((const void*)external_product_generic_big_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
+        if (e != hipSuccess) return e;
+        external_product_generic_big_kernel<<<(unsigned)batch, kBigThreads, big_lds, stream>>>(trgsw, x0, x1, out, ws, s,
+                                                                                             mode, use_lds);
+        return hipGetLastError();
+    }
     const size_t lds = generic_lds_bytes(N, s.K1, s.R);
     hipError_t e = hipFuncSetAttribute((const void*)external_product_generic_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -178,10 +318,21 @@ hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t
 
 hipError_t launch_blind_rotate_generic(const uint32_t* bk, const uint32_t* c, const uint32_t* tv, uint32_t* out,
                                        size_t n_gates, int n, int N, int K, int L, int bg, int extract,
-                                       hipStream_t stream) {
+                                       uint32_t* ws, hipStream_t stream) {
     if (n_gates == 0) return hipSuccess;
     if (!generic_has_kernel(N, K, L)) return hipErrorInvalidValue;
     GenShape s{N, K + 1, L, (K + 1) * L, bg};
+    if (!generic_fits_lds(N, K, L)) {
+        if (!ws) return hipErrorInvalidValue;
+        const int use_lds = N <= kBigLdsN;
+        const size_t big_lds = use_lds ? sizeof(uint32_t) * 2 * (size_t)N : 0;
+        hipError_t e = hipFuncSetAttribute((const void*)blind_rotate_generic_big_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds);
+        if (e != hipSuccess) return e;
+        blind_rotate_generic_big_kernel<<<(unsigned)n_gates, kBigThreads, big_lds, stream>>>(bk, c, tv, out, ws, s, n,
+                                                                                            extract, use_lds);
+        return hipGetLastError();
+    }
     const size_t lds = generic_lds_bytes(N, s.K1, s.R);
     hipError_t e = hipFuncSetAttribute((const void*)blind_rotate_generic_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

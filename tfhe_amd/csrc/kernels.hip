@@ -918,6 +918,63 @@ key_switch_small_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Identity key switch for any decomposition (run-time T and base_bit): the same work split as the
+// kernel above -- one workgroup per (gate, slice of the lv1 coefficients), a thread per output word
+// and 320-word stripe, rows read with coalesced loads from the packed table -- for the bases the
+// tiled kernel has no instantiation for (base_bit >= 4: staging the 2^base_bit - 1 rows of a level
+// in LDS for 64 gates that use at most 64 of them pays no longer).  The digit of a level is the same
+// for the whole workgroup, so a zero digit skips its row without divergence.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kKsSmallThreads)
+key_switch_gather_kernel(const uint32_t* __restrict__ lv1, const uint32_t* __restrict__ ks_packed,
+                         uint32_t* __restrict__ out, int n1, int nlv1, int T, int bb, int rowp, int slices) {
+    __shared__ uint32_t s_dig[kKsSmallMaxSlice];
+    const size_t nr1 = ((size_t)1 << bb) - 1;
+    const int g = blockIdx.x / slices, part = blockIdx.x % slices;
+    const int i_begin = (int)((long)nlv1 * part / slices), i_end = (int)((long)nlv1 * (part + 1) / slices);
+    const int t = threadIdx.x;
+    const uint32_t* lv1_g = lv1 + (size_t)g * (nlv1 + 1);
+    const uint32_t round_offset = 1u << (32 - T * bb - 1), omask = (uint32_t)nr1;
+    const int dshift = 32 - T * bb;
+    for (int w = t; w < rowp; w += kKsSmallThreads) {
+        uint32_t acc = 0u;
+        for (int c0 = i_begin; c0 < i_end; c0 += kKsSmallMaxSlice) {
+            const int count = min(kKsSmallMaxSlice, i_end - c0);
+            __syncthreads();
+            if (t < count) s_dig[t] = (lv1_g[1 + c0 + t] + round_offset) >> dshift;
+            __syncthreads();
+            for (int ii = 0; ii < count; ii++) {
+                const uint32_t d = s_dig[ii];
+                const uint32_t* rows_i = ks_packed + (size_t)(c0 + ii) * T * nr1 * rowp + w;
+                for (int m = 0; m < T; m++) {
+                    const uint32_t o = (d >> ((T - 1 - m) * bb)) & omask;
+                    if (o) acc += rows_i[((size_t)m * nr1 + (o - 1)) * rowp];
+                }
+            }
+        }
+        if (w < n1) {
+            uint32_t v = 0u - acc;
+            if (w == 0 && part == 0) v += lv1_g[0];
+            if (slices == 1) out[(size_t)g * n1 + w] = v;
+            else if (v != 0u) atomicAdd(out + (size_t)g * n1 + w, v);
+        }
+    }
+}
+
+// Zero-fill of the output before the kernels that combine slices with atomic adds.  A kernel, not
+// hipMemsetAsync: a memset node recorded by stream capture replayed a stale fill pattern on the
+// second and later launches of the graph (ROCm 7.0 runtime), and these launchers must be capturable.
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ dst, size_t words) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < words) dst[i] = 0u;
+}
+static hipError_t launch_zero_words(uint32_t* dst, size_t words, hipStream_t stream) {
+    if (words == 0) return hipSuccess;
+    zero_words_kernel<<<(unsigned)((words + 255) / 256), 256, 0, stream>>>(dst, words);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 hipError_t launch_nand_combine(uint32_t* c, const uint32_t* a, const uint32_t* b, size_t n_gates, int n1,
@@ -1009,7 +1066,7 @@ static hipError_t launch_key_switch_inst(const uint32_t* lv1, const uint32_t* ks
     int parts = 1;
     while (tiles * slabs * parts * 2 <= 512 && parts * 2 * 16 <= nlv1) parts *= 2;
     if (parts > 1) {
-        e = hipMemsetAsync(out, 0, (size_t)n_gates * n1 * sizeof(uint32_t), stream);
+        e = launch_zero_words(out, (size_t)n_gates * n1, stream);
         if (e != hipSuccess) return e;
     }
     key_switch_kernel<NR1, MG><<<(unsigned)(tiles * slabs * parts), kKsThreads, lds, stream>>>(
@@ -1017,8 +1074,9 @@ static hipError_t launch_key_switch_inst(const uint32_t* lv1, const uint32_t* ks
     return hipGetLastError();
 }
 
+// every decomposition the reference accepts (src/tlwe_key_switching.hpp:52-60: T * BASE_BIT <= 31)
 bool key_switch_has_kernel(int n1, int T, int bb) {
-    if (bb < 1 || bb > 3 || T < 1 || T * bb > 31) return false;
+    if (bb < 1 || T < 1 || T * bb > 31) return false;
     return n1 >= 1;
 }
 
@@ -1045,10 +1103,22 @@ hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks_packed, uin
         int slices = 1024 / n_gates;
         slices = std::min(slices, nlv1 / 8);
         slices = std::max(slices, (nlv1 + kKsSmallMaxSlice - 1) / kKsSmallMaxSlice);
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)n_gates * n1 * sizeof(uint32_t), stream);
+        hipError_t e = launch_zero_words(out, (size_t)n_gates * n1, stream);
         if (e != hipSuccess) return e;
         key_switch_small_kernel<5, 2><<<(unsigned)(n_gates * slices), kKsSmallThreads, 0, stream>>>(
             lv1, ks_packed, out, n1, nlv1, key_switch_row_words(n1), slices);
+        return hipGetLastError();
+    }
+    if (bb > 3) {
+        // slices: about a thousand workgroups on the GPU, never finer than 8 coefficients
+        int slices = (int)std::max<long>(1, 1024 / n_gates);
+        slices = std::max(1, std::min(slices, nlv1 / 8));
+        if (slices > 1) {
+            hipError_t e = launch_zero_words(out, (size_t)n_gates * n1, stream);
+            if (e != hipSuccess) return e;
+        }
+        key_switch_gather_kernel<<<(unsigned)(n_gates * slices), kKsSmallThreads, 0, stream>>>(
+            lv1, ks_packed, out, n1, nlv1, T, bb, key_switch_row_words(n1), slices);
         return hipGetLastError();
     }
     // MG levels per LDS stage: the largest instantiated divisor of T

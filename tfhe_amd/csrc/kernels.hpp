@@ -50,14 +50,16 @@ hipError_t launch_external_product_512(const NttUniform& u, const d2* tw, const 
 hipError_t launch_external_product_wg(const NttUniform& u, const d2* table, const d2* key_ntt, const uint32_t* x0,
                                       const uint32_t* x1, uint32_t* out, size_t batch, int N, int K, int L, int bg,
                                       int shift, int pack_shift, int pack, int mode, hipStream_t stream);
-// exact O(N^2) kernels for any parameter set (generic_kernels.hip)
+// exact O(N^2) kernels for any parameter set (generic_kernels.hip).  Rings whose per-item state
+// exceeds LDS need a workspace `ws` of generic_big_workspace_words() words (0 = none needed).
 bool generic_has_kernel(int N, int K, int L);
+size_t generic_big_workspace_words(size_t items, int N, int K, int L);
 hipError_t launch_external_product_generic(const uint32_t* trgsw, const uint32_t* x0, const uint32_t* x1,
                                            uint32_t* out, size_t batch, int N, int K, int L, int bg, int mode,
-                                           hipStream_t stream);
+                                           uint32_t* ws, hipStream_t stream);
 hipError_t launch_blind_rotate_generic(const uint32_t* bk, const uint32_t* c, const uint32_t* tv, uint32_t* out,
                                        size_t n_gates, int n, int N, int K, int L, int bg, int extract,
-                                       hipStream_t stream);
+                                       uint32_t* ws, hipStream_t stream);
 bool key_switch_has_kernel(int n1, int T, int bb);
 // the key-switching key is kept on the device without its digit-0 rows, rows padded to
 // key_switch_row_words(n1) words

@@ -88,7 +88,9 @@ struct WgNtt {
 #define TFHE_AMD_WG_EXPERIMENT 0
 #endif
     // timing experiments (wrong results): 1 = every thread reads twiddle row 0 of its group,
-    // 2 = no twiddle loads (thread-uniform values), 3 = no block barrier in the transposes
+    // 2 = no twiddle loads (thread-uniform values), 3 = no block barrier in the transposes,
+    // 4 = no transposition at all, 5 = every key tile read from the first tile's address (wg_kernels.hip),
+    // 6 = aligned instead of rotated accumulator reads (wg_kernels.hip), 7 = no wave-private transposition
     __device__ static __forceinline__ void load_row(Tw7& tw, const d2* rows, int row, const NttUniform& u) {
         if (TFHE_AMD_WG_EXPERIMENT == 2) {
 #pragma unroll
@@ -109,6 +111,8 @@ struct WgNtt {
     // registers in layout `from` -> registers in layout `to`.  bufs: BUF_DOUBLES doubles; `parity`
     // selects the block buffer and is advanced once per block-level transpose.
     __device__ static __forceinline__ void transpose(double (&x)[8], double* bufs, int& parity, int from, int to, int t) {
+        if (TFHE_AMD_WG_EXPERIMENT == 4) return;  // no exchange at all
+        if (TFHE_AMD_WG_EXPERIMENT == 7 && base(from) <= 6 && base(to) <= 6) return;  // no wave-private exchange
         if (base(from) <= 6 && base(to) <= 6) {
             double* wb = bufs + 2 * PAD + (t >> 6) * WAVE_PAD;
 #pragma unroll

@@ -115,8 +115,21 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
     }
     const double unpack = 1.0 / (double)(1u << pack_shift), pack = (double)(1u << pack_shift);
 
+    // -DTFHE_AMD_WG_PHASE_CLOCKS=1: s_memtime stamps around the phases of a step; every wave of gate 0
+    // prints its totals at the end (a diagnostic build: read the shares, not the run time)
+#ifdef TFHE_AMD_WG_PHASE_CLOCKS
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define WPH_START() tprev = __builtin_amdgcn_s_memtime()
+#define WPH_MARK(I) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[I] += tn_ - tprev; tprev = tn_; }
+#define WPH_KEEP(V) asm volatile("" :: "v"(V))
+#else
+#define WPH_START()
+#define WPH_MARK(I)
+#define WPH_KEEP(V)
+#endif
     int parity = 0;
     for (int i = 0; i < n; i++) {
+        WPH_START();
         const int abar = (int)((cg[1 + i] + (1u << (SH - 1))) >> SH);
 
         double acc_ntt[TILES][8];
@@ -133,7 +146,7 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             for (int k = 0; k < 8; k++) {
                 const int sidx = (k * T + t - abar) & (2 * N - 1);
                 const uint32_t neg = 0u - (uint32_t)((sidx >> LOGN) & 1);
-                const uint32_t v = s_acc[q][sidx & (N - 1)];
+                const uint32_t v = s_acc[q][TFHE_AMD_WG_EXPERIMENT == 6 ? k * T + t : sidx & (N - 1)];
                 tw_[k] = ((((v ^ neg) - neg) - s_acc[q][k * T + t]) + offset) ^ flip;
             }
             // The L digit polynomials of this accumulator polynomial are transformed group by group
@@ -149,7 +162,11 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             for (int level = 0; level < L; level++)
 #pragma unroll
                 for (int k = 0; k < 8; k++) x[level][k] = (double)(((int32_t)(tw_[k] << (BG * level))) >> (32 - BG));
+            WPH_KEEP(x[0][0]); WPH_KEEP(x[L - 1][7]);
+            WPH_MARK(0)
             W::template forward_many<SMALL, L, ROWS_IN_LDS>(x, u, table, s_tr, parity, t, s_rows);  // |x| <= 3.2 p
+            WPH_KEEP(x[0][0]); WPH_KEEP(x[L - 1][7]);
+            WPH_MARK(1)
 #pragma unroll
             for (int level = 0; level < L; level++) {
 #pragma unroll
@@ -157,7 +174,8 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                     const int next = level * TILES + tile + 1;
                     if (next < L * TILES) {
 #pragma unroll
-                        for (int kk = 0; kk < 4; kk++) ynext[kk] = bk_poly[(size_t)next * (N / 2) + kk * T + t];
+                        for (int kk = 0; kk < 4; kk++)
+                            ynext[kk] = bk_poly[(size_t)(TFHE_AMD_WG_EXPERIMENT == 5 ? 0 : next) * (N / 2) + kk * T + t];
                     }
                     // the eight products of a tile phase by phase (ntt512.hpp): dependent FP64
                     // instructions end up eight apart instead of back to back
@@ -181,9 +199,13 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
                     for (int tile = 0; tile < TILES; tile++) reduce_n<8>(acc_ntt[tile], p, pinv);
                 }
             }
+            WPH_KEEP(acc_ntt[0][0]); WPH_KEEP(acc_ntt[TILES - 1][7]);
+            WPH_MARK(2)
         }
         // all K1 + PACKS inverse transforms group by group: one load of every twiddle row serves them all
         W::template inverse_many<TILES, ROWS_IN_LDS>(acc_ntt, u, table, s_tr, parity, t, s_rows);
+        WPH_KEEP(acc_ntt[0][0]); WPH_KEEP(acc_ntt[TILES - 1][7]);
+        WPH_MARK(3)
 #pragma unroll
         for (int col = 0; col < K1; col++) {
             // the packed accumulator holds the small exact hi sums of two columns: h_even + 2^pack_shift h_odd
@@ -202,8 +224,15 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
             for (int k = 0; k < 8; k++)
                 s_acc[col][k * T + t] += to_torus(acc_ntt[col][k], p, pinv) + (hi_sum[k] << shift);
         }
+        WPH_MARK(4)
         __syncthreads();
+        WPH_MARK(5)
     }
+#ifdef TFHE_AMD_WG_PHASE_CLOCKS
+    if (gate == 0 && (t & 63) == 0)
+        printf("wave %d ticks: prep %llu forward %llu products %llu inverse %llu update %llu barrier %llu\n", t >> 6, ph[0],
+               ph[1], ph[2], ph[3], ph[4], ph[5]);
+#endif
 
     if (!extract) {
         uint32_t* o = out + gate * (size_t)(K1 * N);
