@@ -131,6 +131,36 @@ def test_latency_and_throughput_forms_agree(keys, octx):
             assert np.array_equal(ctx.blind_rotate(c[:2])[0], octx.blind_rotate(c[0])), form
 
 
+@pytest.mark.parametrize("gates", [2048 + 5, 2048 + 512, 2048 + 513])
+def test_ragged_batch_tail_on_the_workgroup_form(keys, ctx, octx, gates):
+    """A batch just above a whole generation of resident waves: a remainder of up to 512 gates runs in
+    the workgroup-per-gate form behind the wave-per-gate kernel (513: it does not).
+    Every word equals the pinned wave-per-gate form's, the first and last gates (both sides of the split)
+    equal the oracle's, and the same buffers are reused twice without a device-wide synchronisation."""
+    import tfhe_amd
+    import torch
+
+    p, s0, _, bk, ks = keys
+    bits_a, bits_b, a, b = _inputs(p, s0, gates, seed=gates)
+    da = torch.from_numpy(a.view(np.int32)).cuda()
+    db = torch.from_numpy(b.view(np.int32)).cuda()
+    out1, out2 = torch.empty_like(da), torch.empty_like(da)
+    ctx.nand_device(da, db, out1)
+    ctx.nand_device(out1, db, out2)          # consumes the first call's output on the same stream
+    ctx.synchronize()
+    got1, got2 = out1.cpu().numpy().view(np.uint32), out2.cpu().numpy().view(np.uint32)
+    with tfhe_amd.Context(tfhe_amd.params_default(), bk, ks, form="throughput") as pinned:
+        ref1, ref2 = torch.empty_like(da), torch.empty_like(da)
+        pinned.nand_device(da, db, ref1)
+        pinned.nand_device(ref1, db, ref2)
+        pinned.synchronize()
+    assert np.array_equal(got1, ref1.cpu().numpy().view(np.uint32))
+    assert np.array_equal(got2, ref2.cpu().numpy().view(np.uint32))
+    sample = [0, 1, 2047, 2048, gates - 2, gates - 1]
+    assert np.array_equal(got1[sample], octx.nand_batch(a[sample], b[sample]))
+    assert np.array_equal(O.decrypt_bits(got1, s0, p), 1 - (bits_a & bits_b))
+
+
 def test_config4_ripple_carry_adder(keys, ctx, octx):
     """32-bit ripple-carry adder from NAND only, gates batched per dependency level, wires
     resident on the GPU.  Decrypted sum = a + b; on an 8-bit instance every wire equals the

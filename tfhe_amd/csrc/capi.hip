@@ -485,9 +485,28 @@ int run_blind_rotate(tfhe_amd_ctx* ctx, const uint32_t* c, const uint32_t* tv, u
     if (ctx->replica)
         HIP_TRY(launch_blind_rotate_replica(ctx->d_spec, ctx->d_tw, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit,
                                             extract, ctx->replica_generic ? 1 : 0, s));
-    else if (ctx->fast)
+    else if (ctx->fast) {
+        // The wave-per-gate form keeps kResident gates in flight and a workgroup runs all n steps, so a
+        // batch that is not a multiple of kResident pays a whole extra generation (about 7 ms at the
+        // default set) for its remainder.  A remainder of up to two gates per CU goes through the
+        // workgroup-per-gate form instead, behind the rest on the same stream (2.3 ms per 256 gates).
+        // Identical results: the two forms compute the same words.  Measured alternatives: the remainder
+        // ahead of the rest on a second stream costs more (the CUs it delays run their four generations
+        // out of step with their neighbours and fetch every key row from the Infinity Cache on their own).
+        constexpr size_t kResident = 2048, kTailMax = 512;
+        const size_t tail = n_gates % kResident;
+        if (ctx->form == 0 && n_gates > kResident && tail > 0 && tail <= kTailMax) {
+            const size_t head = n_gates - tail;
+            const size_t out_row = extract ? lv1_of(ctx) : trlwe_of(ctx);
+            HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)head, p.n, p.K, p.L, extract, 2,
+                                            s));
+            HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c + head * n1_of(ctx), tv, out + head * out_row,
+                                            (int)tail, p.n, p.K, p.L, extract, 1, s));
+            return TFHE_AMD_OK;
+        }
         HIP_TRY(launch_blind_rotate_512(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, (int)n_gates, p.n, p.K, p.L,
                                         extract, ctx->form, s));
+    }
     else if (ctx->wg)
         HIP_TRY(launch_blind_rotate_wg(ctx->u, ctx->d_tw, ctx->d_bk_ntt, c, tv, out, n_gates, p.n, p.N, p.K, p.L, p.bg_bit,
                                        ctx->shift, ctx->pack_shift, ctx->pack, extract, s));

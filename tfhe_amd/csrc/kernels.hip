@@ -494,6 +494,10 @@ external_product_512_kernel(const NttUniform u, const d2* __restrict__ tw, const
 // that pairs the halves: 2.31 ms per gate against 2.26 ms; six waves, one per transform: 2.74 ms).
 // Same arithmetic, same results.  `tw_half`: the table of ntt512_half.hpp.
 // ------------------------------------------------------------------------------------------
+// key rows requested this many steps ahead of their use (1 or 2)
+#ifndef TFHE_AMD_LATENCY_KEY_AHEAD
+#define TFHE_AMD_LATENCY_KEY_AHEAD 1
+#endif
 template <int K, int L>
 __global__ void __launch_bounds__(128 * (K + 1) * L, 1)
 blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_half, const d2* __restrict__ bk_ntt,
@@ -543,12 +547,24 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
     // phase 2 wants i = 4 lane + k.
     const int put_at = pair_slot(128 * h + 2 * lane) / 2, get_at = pair_slot(4 * lane) / 2;
     d2 y[K1][2], ynext[K1][2];
+#if TFHE_AMD_LATENCY_KEY_AHEAD == 2
+    d2 ynext2[K1][2];
+#endif
     {
         const d2* bk_poly = bk_ntt + (size_t)r * K1 * (kN / 2) + key_off;
 #pragma unroll
         for (int col = 0; col < K1; col++)
 #pragma unroll
             for (int t = 0; t < 2; t++) ynext[col][t] = bk_poly[col * (kN / 2) + t * 64];
+#if TFHE_AMD_LATENCY_KEY_AHEAD == 2
+        if (n > 1) {
+            const d2* bk_poly1 = bk_poly + (size_t)R * K1 * (kN / 2);
+#pragma unroll
+            for (int col = 0; col < K1; col++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) ynext2[col][t] = bk_poly1[col * (kN / 2) + t * 64];
+        }
+#endif
     }
 #ifdef TFHE_AMD_LATENCY_CLOCKS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -570,6 +586,19 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
         for (int col = 0; col < K1; col++)
 #pragma unroll
             for (int t = 0; t < 2; t++) y[col][t] = ynext[col][t];
+#if TFHE_AMD_LATENCY_KEY_AHEAD == 2
+#pragma unroll
+        for (int col = 0; col < K1; col++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) ynext[col][t] = ynext2[col][t];
+        if (i + 2 < n) {
+            const d2* bk_poly = bk_ntt + ((size_t)(i + 2) * R + r) * K1 * (kN / 2) + key_off;
+#pragma unroll
+            for (int col = 0; col < K1; col++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) ynext2[col][t] = bk_poly[col * (kN / 2) + t * 64];
+        }
+#else
         if (i + 1 < n) {
             const d2* bk_poly = bk_ntt + ((size_t)(i + 1) * R + r) * K1 * (kN / 2) + key_off;
 #pragma unroll
@@ -577,6 +606,7 @@ blind_rotate_512_latency_kernel(const NttUniform u, const d2* __restrict__ tw_ha
 #pragma unroll
                 for (int t = 0; t < 2; t++) ynext[col][t] = bk_poly[col * (kN / 2) + t * 64];
         }
+#endif
         double d[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -1108,6 +1138,22 @@ hipError_t launch_key_switch(const uint32_t* lv1, const uint32_t* ks_packed, uin
         key_switch_small_kernel<5, 2><<<(unsigned)(n_gates * slices), kKsSmallThreads, 0, stream>>>(
             lv1, ks_packed, out, n1, nlv1, key_switch_row_words(n1), slices);
         return hipGetLastError();
+    }
+    // The tiled kernel is bound by the LDS of a CU: two workgroups on one CU take twice as long as one,
+    // so a batch a little above a whole number of workgroups per CU (256 workgroups = 8,192 gates at the
+    // default row length) would pay a full extra round for its remainder.  The remainder is launched on
+    // its own instead, where it gets the slicing of a small batch and spreads over all CUs.
+    if (bb <= 3) {
+        const int slabs = key_switch_row_words(n1) / kKsSlab;
+        const int round_gates = kKsTile * std::max(1, 256 / slabs);
+        const int rem = n_gates % round_gates;
+        if (n_gates > round_gates && rem != 0) {
+            const int head = n_gates - rem;
+            hipError_t e = launch_key_switch(lv1, ks_packed, out, head, n1, nlv1, T, bb, stream);
+            if (e != hipSuccess) return e;
+            return launch_key_switch(lv1 + (size_t)head * (nlv1 + 1), ks_packed, out + (size_t)head * n1, rem, n1, nlv1, T,
+                                     bb, stream);
+        }
     }
     if (bb > 3) {
         // slices: about a thousand workgroups on the GPU, never finer than 8 coefficients
