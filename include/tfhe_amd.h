@@ -102,12 +102,16 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx* ctx);
  * (src/tlwe_key_switching.hpp:26-45).  s_lv0: [n] bytes 0/1 (SecretKey::tlwe_lv0_s); s_ring:
  * [K][N] bytes 0/1 (SecretKey::trlwe_s), both in HOST memory.  alpha_lv0 / alpha_lv1: noise standard
  * deviations of the lv0 TLWE and of the ring (reference src/tlwe.hpp:13, src/trlwe.hpp:12).  Every
- * mask and noise word is ChaCha20 output under the 256-bit key `seed` (eight words): the result is
- * a pure function of (secret key, seed), and the masks are as unpredictable as the seed, which must
- * therefore be fresh secret randomness (the reference draws every word from std::random_device,
- * src/random.hpp:10,35-41); a fixed seed is for tests.  Generated keys cannot be compared with
- * reference bytes (the reference is not reproducible); they are checked word for word against the
- * CPU oracle's restatement of the same generator and through their decryption.
+ * mask word and every noise sample is derived from ChaCha20 output under the 256-bit key `seed` (eight
+ * words), and the masks are as unpredictable as the seed, which must therefore be fresh secret
+ * randomness (the reference draws every word from std::random_device, src/random.hpp:10,35-41); a
+ * fixed seed is for tests.  On one GPU and library build the result is a pure function of (secret
+ * key, seed).  The mask words are pure integer functions of the seed; a noise word goes through
+ * log, sin and cos (Box-Muller) and may differ by one unit of 2^-32 between math libraries, so the
+ * b words are reproducible across machines only up to that unit.  Generated keys cannot be compared
+ * with reference bytes (the reference is not reproducible); they are checked against the CPU oracle's
+ * restatement of the same generator (masks identical, noise words within one unit) and through
+ * their decryption.
  *   _keygen:        raw keys to HOST arrays bk / ks (either may be NULL)
  *   _keygen_device: raw keys to DEVICE arrays on GPU `device`, synchronised before returning
  *   _ctx_create_from_secret: keys generated on the GPU and turned into a context without

@@ -245,3 +245,31 @@ def test_nand_sharded_gloo_world2_on_gpu():
         pr.join(240)
         assert pr.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher's environment: the script starts its two ranks itself
+    (fresh processes, before the parent touches a GPU), rank 0's JSON line comes back, every rank's
+    outputs decrypt correctly.  gloo stands in for RCCL here (one GPU shared by the ranks); the strong
+    (fixed total, block split) and the weak sizing are both run at a small size."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["TFHE_BENCH_BACKEND"] = "gloo"
+    for extra, scaling, per_rank in ((["--gates-per-gpu", "96"], "weak", [96, 96]), (["--total-gates", "131"], "strong", [65, 66])):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                            "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling
+        assert line["distributed"]["world_size"] == 2 and line["distributed"]["launcher"] == "self"
+        assert [e["gates"] for e in line["distributed"]["per_rank"]] == per_rank
+        assert line["verified"] == {**line["verified"], "gates_decrypted": sum(per_rank), "wrong": 0}
+    # a rank that fails takes the whole launch down with a non-zero status
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--gates-per-gpu", "-5"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0

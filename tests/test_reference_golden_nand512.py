@@ -1,5 +1,5 @@
 """Known-answer test at the DEFAULT parameters against the compiled reference, without needing the
-reference at test time: tests/golden/refnand512.npz (made by oracle/make_golden_nand512.py) holds 8
+reference at test time: tests/golden/refnand512.npz (made by oracle/make_golden_nand512.py) holds 48
 input pairs and the ciphertexts HomNAND<>::nand of the real reference returned for them under an
 evaluation key regenerated here from the recorded seed (its checksum is recorded too).  With the
 reference's FFT product replayed, the oracle and the GPU must return exactly those ciphertexts;
@@ -30,7 +30,7 @@ def case(golden):
 
 def test_oracle_replay_equals_recorded_reference_output(case):
     p, g, bk, ks = case
-    for i in (0, 5):
+    for i in (0, 5, 8, 47):
         assert np.array_equal(O.nand(g["a"][i], g["b"][i], bk, ks, p, 2), g["out"][i])
     exact = O.Context(p, bk, ks).nand_batch(g["a"], g["b"])
     want = 1 - (g["bits_a"] & g["bits_b"])
