@@ -437,6 +437,39 @@ __device__ __forceinline__ void transpose_b_to_a(double (&x)[8], double* tr, int
     wave_lds_fence();
 }
 
+// The first two stages of a forward transform of 8-bit gadget digits (|x| <= 2^7), on the eight
+// registers of a lane (pairs (k, k + 4), then (k, k + 2)), with no modular reduction at all.  With
+// I = zeta^2 and zeta^4 = -1 the twiddles are I (stage 1), zeta (stage 2, registers 0..3) and zeta^3
+// (stage 2, registers 4..7).  Stage 1 gives x_k +- I x_(k+4), below 2^32.4.  The zeta^3 products are
+// taken from the original digits: zeta^3 (x_2 - I x_6) = zeta (I x_2 + x_6), so every value stays an
+// exact integer below 2^45.2 and the two butterflies that would need a full modular product (six
+// instructions each) cost one fused multiply-add per output instead.
+__device__ __forceinline__ void small_first_two_stages(double (&x)[8], const NttUniform& u) {
+    const double d2 = x[2], d3 = x[3], d6 = x[6], d7 = x[7];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double a = x[k], b = x[k + 4];
+        x[k] = __builtin_fma(b, u.zI, a);
+        x[k + 4] = __builtin_fma(-b, u.zI, a);
+    }
+    x[2] = __builtin_fma(d6, u.zI, d2);
+    x[3] = __builtin_fma(d7, u.zI, d3);
+    const double u2 = __builtin_fma(d2, u.zI, d6), u3 = __builtin_fma(d3, u.zI, d7);
+    pin();
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double a = x[k], b = x[k + 2];
+        x[k] = __builtin_fma(b, u.z, a);
+        x[k + 2] = __builtin_fma(-b, u.z, a);
+    }
+    const double a4 = x[4], a5 = x[5];
+    x[4] = __builtin_fma(u2, u.z, a4);
+    x[6] = __builtin_fma(-u2, u.z, a4);
+    x[5] = __builtin_fma(u3, u.z, a5);
+    x[7] = __builtin_fma(-u3, u.z, a5);
+    pin();
+}
+
 // Forward transform.  In: layout A, |x| <= 2^31 (SMALL: |x| <= 2^7, 8-bit gadget digits).
 // Out: layout C (bit-reversed spectrum order); |x| <= p/2 with FINAL_REDUCE, else |x| <= 3.2 p.
 //
@@ -477,31 +510,7 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform&
     if (PIN) {
         // same arithmetic as below, butterflies issued phase by phase
         if (SMALL) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const double a = x[k], b = x[k + 4];
-                x[k] = __builtin_fma(b, u.zI, a);
-                x[k + 4] = __builtin_fma(-b, u.zI, a);
-            }
-            pin();
-            double b2[2], w2[2], wp2[2], t2[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const double a = x[k], b = x[k + 2];
-                x[k] = __builtin_fma(b, u.z, a);
-                x[k + 2] = __builtin_fma(-b, u.z, a);
-                b2[k] = x[k + 6];
-                w2[k] = u.fw[3];
-                wp2[k] = u.fwp[3];
-            }
-            mulmod_tw_n<2>(t2, b2, w2, wp2, p);
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const double a = x[k + 4];
-                x[k + 6] = a - t2[k];
-                x[k + 4] = a + t2[k];
-            }
-            pin();
+            small_first_two_stages(x, u);
             ct_stage_pinned<1, false>(x, u.fw + 1, u.fwp + 1, p, pinv);
         } else {
             ct8_pinned<false>(x, u.fw + 1, u.fwp + 1, p, pinv);
@@ -517,23 +526,7 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform&
         return;
     }
     if (SMALL) {
-        // distance 256, twiddle zeta^2 < 2^26: |x * zeta^2| < 2^33, no reduction needed
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double a = x[k], b = x[k + 4];
-            x[k] = __builtin_fma(b, u.zI, a);
-            x[k + 4] = __builtin_fma(-b, u.zI, a);
-        }
-        // distance 128: first half twiddle zeta < 2^13 (|x * zeta| < 2^46, still unreduced and
-        // far below p), second half twiddle zeta^3, reduced
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const double a = x[k], b = x[k + 2];
-            x[k] = __builtin_fma(b, u.z, a);
-            x[k + 2] = __builtin_fma(-b, u.z, a);
-        }
-#pragma unroll
-        for (int k = 4; k < 6; k++) bf_ct(x[k], x[k + 2], u.fw[3], u.fwp[3], p);
+        small_first_two_stages(x, u);
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) bf_ct(x[k], x[k + 4], u.fw[1], u.fwp[1], p);
@@ -560,35 +553,10 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform&
 }
 
 // First stage group of the forward transform of 8-bit digits (layout A), phase-ordered: the
-// distance-256 and the first distance-128 twiddles are small enough to need no reduction.
+// distance-256 and distance-128 stages need no reduction (small_first_two_stages).
 __device__ __forceinline__ void ct8_small_first(double (&x)[8], const NttUniform& u) {
-    const double p = u.p, pinv = u.pinv;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const double a = x[k], b = x[k + 4];
-        x[k] = __builtin_fma(b, u.zI, a);
-        x[k + 4] = __builtin_fma(-b, u.zI, a);
-    }
-    pin();
-    double b2[2], w2[2], wp2[2], t2[2];
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const double a = x[k], b = x[k + 2];
-        x[k] = __builtin_fma(b, u.z, a);
-        x[k + 2] = __builtin_fma(-b, u.z, a);
-        b2[k] = x[k + 6];
-        w2[k] = u.fw[3];
-        wp2[k] = u.fwp[3];
-    }
-    mulmod_tw_n<2>(t2, b2, w2, wp2, p);
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const double a = x[k + 4];
-        x[k + 6] = a - t2[k];
-        x[k + 4] = a + t2[k];
-    }
-    pin();
-    ct_stage_pinned<1, false>(x, u.fw + 1, u.fwp + 1, p, pinv);
+    small_first_two_stages(x, u);
+    ct_stage_pinned<1, false>(x, u.fw + 1, u.fwp + 1, u.p, u.pinv);
 }
 
 // Two forward transforms of 8-bit digit polynomials, interleaved group by group so that one's

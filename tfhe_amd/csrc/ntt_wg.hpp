@@ -229,20 +229,7 @@ struct WgNtt {
         for (int m = 0; m < M; m++) {
             double (&x)[8] = xs[m];
             if (SMALL == 1) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const double a = x[k], b = x[k + 4];
-                    x[k] = __builtin_fma(b, u.zI, a);
-                    x[k + 4] = __builtin_fma(-b, u.zI, a);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const double a = x[k], b = x[k + 2];
-                    x[k] = __builtin_fma(b, u.z, a);
-                    x[k + 2] = __builtin_fma(-b, u.z, a);
-                }
-#pragma unroll
-                for (int k = 4; k < 6; k++) bf_ct(x[k], x[k + 2], u.fw[3], u.fwp[3], p);
+                small_first_two_stages(x, u);  // no reduction in either stage (ntt512.hpp)
             } else if (SMALL == 2) {
                 // |x * zeta^2| < 2^41.3: exact, far below p
 #pragma unroll
