@@ -384,17 +384,33 @@ struct TrPrio {
     __device__ __forceinline__ ~TrPrio() { if (TFHE_AMD_TR_SETPRIO) __builtin_amdgcn_s_setprio(0); }
 };
 
+// Slots of the exchange between layouts A and B.  A pad slot per 64 positions (slot = j + 8 (j >> 6))
+// keeps both sides free of bank conflicts: a 32-lane group of layout A reads 32 consecutive doubles,
+// one of layout B four runs of eight that start 72 doubles = 8 banks-of-doubles (mod 32) apart; the
+// 16-lane groups of the stores see the same pattern mod 16.  The pad slot per 8 positions that the
+// exchange between B and C needs (pad_pos) puts lanes 0..2 and 29..31 of a layout-A group on the same
+// banks: 1.25e9 conflict cycles per 8,192 gates, all of them from these two functions.
+// -DTFHE_AMD_TR_PAD_AB=0 selects that older form.
+#ifndef TFHE_AMD_TR_PAD_AB
+#define TFHE_AMD_TR_PAD_AB 1
+#endif
+__device__ __forceinline__ int ab_slot_a(int k, int lane) {
+    return TFHE_AMD_TR_PAD_AB ? 72 * k + lane : pad_pos(64 * k + lane);
+}
+__device__ __forceinline__ int ab_slot_b(int k, int lane) {
+    return 72 * (lane >> 3) + (lane & 7) + (TFHE_AMD_TR_PAD_AB ? 8 : 9) * k;
+}
+
 __device__ __forceinline__ void transpose_a_to_b(double (&x)[8], double* tr, int lane) {
 #ifdef TFHE_AMD_EXPERIMENT_NO_TRANSPOSE
     return;  // timing experiment (wrong results): what the exchanges cost
 #endif
     TrPrio prio;
 #pragma unroll
-    for (int k = 0; k < 8; k++) tr[pad_pos(64 * k + lane)] = x[k];
+    for (int k = 0; k < 8; k++) tr[ab_slot_a(k, lane)] = x[k];
     wave_lds_fence();
-    const int base = 72 * (lane >> 3) + (lane & 7);
 #pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = tr[base + 9 * k];
+    for (int k = 0; k < 8; k++) x[k] = tr[ab_slot_b(k, lane)];
     wave_lds_fence();
 }
 __device__ __forceinline__ void transpose_b_to_c(double (&x)[8], double* tr, int lane) {
@@ -428,12 +444,11 @@ __device__ __forceinline__ void transpose_b_to_a(double (&x)[8], double* tr, int
     return;  // timing experiment (wrong results): what the exchanges cost
 #endif
     TrPrio prio;
-    const int base = 72 * (lane >> 3) + (lane & 7);
 #pragma unroll
-    for (int k = 0; k < 8; k++) tr[base + 9 * k] = x[k];
+    for (int k = 0; k < 8; k++) tr[ab_slot_b(k, lane)] = x[k];
     wave_lds_fence();
 #pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = tr[pad_pos(64 * k + lane)];
+    for (int k = 0; k < 8; k++) x[k] = tr[ab_slot_a(k, lane)];
     wave_lds_fence();
 }
 

@@ -90,7 +90,8 @@ struct WgNtt {
     // timing experiments (wrong results): 1 = every thread reads twiddle row 0 of its group,
     // 2 = no twiddle loads (thread-uniform values), 3 = no block barrier in the transposes,
     // 4 = no transposition at all, 5 = every key tile read from the first tile's address (wg_kernels.hip),
-    // 6 = aligned instead of rotated accumulator reads (wg_kernels.hip), 7 = no wave-private transposition
+    // 6 = aligned instead of rotated accumulator reads (wg_kernels.hip), 7 = no wave-private transposition,
+    // 8 = the key rows of steps 0..7 in rotation (all key reads hit L2; wg_kernels.hip)
     __device__ static __forceinline__ void load_row(Tw7& tw, const d2* rows, int row, const NttUniform& u) {
         if (TFHE_AMD_WG_EXPERIMENT == 2) {
 #pragma unroll
@@ -115,11 +116,18 @@ struct WgNtt {
         if (TFHE_AMD_WG_EXPERIMENT == 7 && base(from) <= 6 && base(to) <= 6) return;  // no wave-private exchange
         if (base(from) <= 6 && base(to) <= 6) {
             double* wb = bufs + 2 * PAD + (t >> 6) * WAVE_PAD;
+            // One pad run per 2^a positions, a = the larger of the two bases (at least 3), 2^(a-3) slots
+            // long: a 32-lane group of the layout with base a then reads consecutive doubles and one of
+            // the other layout runs that start a multiple of 2^(a-3) banks-of-doubles apart, so neither
+            // side has a bank conflict (with the pad slot per 8 positions of pad_pos for every exchange,
+            // a base above 3 put the ends of its 2^a-runs on the same banks).
+            const int a = (base(from) > base(to) ? base(from) : base(to)) < 3 ? 3 : (base(from) > base(to) ? base(from) : base(to));
+            auto slot = [a](int j) { return TFHE_AMD_TR_PAD_AB ? j + ((j >> a) << (a - 3)) : pad_pos(j); };
 #pragma unroll
-            for (int k = 0; k < 8; k++) wb[pad_pos(position(from, t, k) & 511)] = x[k];
+            for (int k = 0; k < 8; k++) wb[slot(position(from, t, k) & 511)] = x[k];
             wave_lds_fence();
 #pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = wb[pad_pos(position(to, t, k) & 511)];
+            for (int k = 0; k < 8; k++) x[k] = wb[slot(position(to, t, k) & 511)];
             wave_lds_fence();
             return;
         }

@@ -138,7 +138,8 @@ blind_rotate_wg_kernel(const NttUniform u, const d2* __restrict__ table, const d
 #pragma unroll
             for (int k = 0; k < 8; k++) acc_ntt[tile][k] = 0.0;
 
-        const d2* bk_row = bk_ntt + (size_t)i * (R * TILES) * (N / 2);
+        // experiment 8 (wrong results): eight key rows in rotation, which stay in the XCD's L2
+        const d2* bk_row = bk_ntt + (size_t)(TFHE_AMD_WG_EXPERIMENT == 8 ? (i & 7) : i) * (R * TILES) * (N / 2);
 #pragma unroll 1
         for (int q = 0; q < K1; q++) {
             uint32_t tw_[8];
