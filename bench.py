@@ -285,8 +285,12 @@ def main_rank(args):
     dev_index = local_rank if backend == "nccl" else local_rank % max(n_dev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # TFHE_BENCH_FORCE_DIST=1: a single rank still creates the process group and runs the key broadcast,
+    # the gathers and the barriers through it (RCCL with one GPU), so that path can be tested on one GPU
+    use_dist = world > 1 or os.environ.get("TFHE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -318,7 +322,7 @@ def main_rank(args):
         bk = torch.empty(bk_words, dtype=torch.int32, device=bcast_dev)
         ks = torch.empty(ks_words, dtype=torch.int32, device=bcast_dev)
     t_bcast = 0.0
-    if world > 1:
+    if use_dist:
         # the first collective creates the communicator: keep it out of the broadcast time
         warm = torch.zeros(1, dtype=torch.int32, device=bcast_dev)
         dist.broadcast(warm, src=0)
@@ -353,7 +357,7 @@ def main_rank(args):
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -372,7 +376,7 @@ def main_rank(args):
     ctx.enable_timing(False)
     # per-rank times and kernel times to rank 0; the job's time is the slowest rank's
     mine = torch.tensor([elapsed_local, br_ms / max(calls, 1), float(G)], dtype=torch.float64, device=bcast_dev)
-    if world > 1:
+    if use_dist:
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
     else:
@@ -382,7 +386,7 @@ def main_rank(args):
     # every rank decrypts what its last timed step produced and checks it against the plaintext NAND
     wrong_local = int(np.count_nonzero(enc.decrypt(out.cpu().numpy().view(np.uint32)) != 1 - (bits_a & bits_b)))
     wrong = torch.tensor([wrong_local], dtype=torch.int64, device=bcast_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(wrong, op=dist.ReduceOp.SUM)
     wrong = int(wrong.item())
 
@@ -413,8 +417,8 @@ def main_rank(args):
                          "key_switch_kernel_ms": ks_ms / max(calls, 1),
                          "io_GBps": IO_BYTES_PER_GATE * G / (elapsed / args.steps) / 1e9,
                          "note": "peak = 39.3e12 FP64 lane-instructions/s / 7.69 FP64 instructions per modmul-equivalent"},
-            "distributed": {"backend": backend if world > 1 else "none",
-                            "world_size": dist.get_world_size() if world > 1 else 1,
+            "distributed": {"backend": backend if use_dist else "none",
+                            "world_size": dist.get_world_size() if use_dist else 1,
                             "launcher": "self" if os.environ.get("TFHE_BENCH_SELF_LAUNCHED") else
                                         ("external" if world > 1 else "none"),
                             "key_broadcast_s": t_bcast,
@@ -491,7 +495,7 @@ def main_rank(args):
             line["cpu_baseline"] = cpu_baseline(p, args.cpu_sample_gates, threads)
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if wrong:
         raise SystemExit(f"bench: {wrong} results decrypted to the wrong value")

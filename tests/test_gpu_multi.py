@@ -273,3 +273,27 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--gates-per-gpu", "-5"],
                        env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode != 0
+
+
+def test_bench_single_rank_through_rccl():
+    """The benchmark's collective path with the real backend: one rank creates an RCCL process group on its
+    GPU and runs the key broadcasts, the barriers, the gather of the per-rank times and the reduction of the
+    wrong-bit count through it (gloo stands in for RCCL in the two-rank test above, because two RCCL ranks
+    cannot share one GPU).  The line must say that RCCL ran, and every output must decrypt correctly."""
+    import json
+    import pathlib
+    import subprocess
+    import sys
+
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TFHE_BENCH_BACKEND")}
+    env["TFHE_BENCH_FORCE_DIST"] = "1"
+    env["MASTER_PORT"] = "29547"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--gates-per-gpu", "160", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["distributed"]["backend"] == "nccl" and line["distributed"]["world_size"] == 1
+    assert line["distributed"]["key_broadcast_s"] > 0.0
+    assert line["verified"] == {**line["verified"], "gates_decrypted": 160, "wrong": 0}
