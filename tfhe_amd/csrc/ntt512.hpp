@@ -567,6 +567,10 @@ __device__ __forceinline__ void ntt512_forward(double (&x)[8], const NttUniform&
     }
 }
 
+#ifndef TFHE_AMD_TW_EARLY
+#define TFHE_AMD_TW_EARLY 1
+#endif
+
 // First stage group of the forward transform of 8-bit digits (layout A), phase-ordered: the
 // distance-256 and distance-128 stages need no reduction (small_first_two_stages).
 __device__ __forceinline__ void ct8_small_first(double (&x)[8], const NttUniform& u) {
@@ -582,36 +586,43 @@ template <typename Between>
 __device__ __forceinline__ void ntt512_forward2_small(double (&a)[8], double (&b)[8], const NttUniform& u, const d2* s_tw,
                                                       double* tra, double* trb, int lane, Between between) {
     const double p = u.p, pinv = u.pinv;
+    // LDS instructions of a wave complete in issue order.  A stage group's twiddle row is therefore
+    // requested BEFORE the partner's exchange is issued (TFHE_AMD_TW_EARLY): requested behind it, the
+    // row would arrive only after that exchange has completed, and the group that is meant to cover
+    // the exchange would wait for it instead.
     ct8_small_first(a, u);
     transpose_a_to_b(a, tra, lane);
+    Tw7 t, t2;
+    if (TFHE_AMD_TW_EARLY) load_tw7(t, s_tw + kTwFwdB + 7 * (lane >> 3));
     ct8_small_first(b, u);
     transpose_a_to_b(b, trb, lane);
-    Tw7 t;
-    load_tw7(t, s_tw + kTwFwdB + 7 * (lane >> 3));
+    if (!TFHE_AMD_TW_EARLY) load_tw7(t, s_tw + kTwFwdB + 7 * (lane >> 3));
     ct8_pinned<false>(a, t.w, t.wp, p, pinv);
     transpose_b_to_c(a, tra, lane);
+    if (TFHE_AMD_TW_EARLY) load_tw7(t2, s_tw + kTwFwdC + 7 * lane);
     ct8_pinned<false>(b, t.w, t.wp, p, pinv);
     transpose_b_to_c(b, trb, lane);
-    load_tw7(t, s_tw + kTwFwdC + 7 * lane);
-    ct8_pinned<true>(a, t.w, t.wp, p, pinv);
+    if (!TFHE_AMD_TW_EARLY) load_tw7(t2, s_tw + kTwFwdC + 7 * lane);
+    ct8_pinned<true>(a, t2.w, t2.wp, p, pinv);
     between();
-    ct8_pinned<true>(b, t.w, t.wp, p, pinv);
+    ct8_pinned<true>(b, t2.w, t2.wp, p, pinv);
 }
 
 // Two inverse transforms interleaved the same way; arithmetic and bounds of ntt512_inverse<true>.
 __device__ __forceinline__ void ntt512_inverse2(double (&a)[8], double (&b)[8], const NttUniform& u, const d2* s_tw,
                                                 double* tra, double* trb, int lane) {
     const double p = u.p, pinv = u.pinv;
-    Tw7 t;
+    Tw7 t, t2;
     load_tw7(t, s_tw + kTwInvC + 7 * lane);
     gs8_planned<2>(a, t.w, t.wp, p, pinv);
     transpose_c_to_b(a, tra, lane);
+    if (TFHE_AMD_TW_EARLY) load_tw7(t2, s_tw + kTwInvB + 7 * (lane >> 3));  // ahead of b's exchange (see above)
     gs8_planned<2>(b, t.w, t.wp, p, pinv);
     transpose_c_to_b(b, trb, lane);
-    load_tw7(t, s_tw + kTwInvB + 7 * (lane >> 3));
-    gs8_planned<1>(a, t.w, t.wp, p, pinv);
+    if (!TFHE_AMD_TW_EARLY) load_tw7(t2, s_tw + kTwInvB + 7 * (lane >> 3));
+    gs8_planned<1>(a, t2.w, t2.wp, p, pinv);
     transpose_b_to_a(a, tra, lane);
-    gs8_planned<1>(b, t.w, t.wp, p, pinv);
+    gs8_planned<1>(b, t2.w, t2.wp, p, pinv);
     transpose_b_to_a(b, trb, lane);
     gs8_planned<0>(a, u.iw + 1, u.iwp + 1, p, pinv);
     gs8_planned<0>(b, u.iw + 1, u.iwp + 1, p, pinv);

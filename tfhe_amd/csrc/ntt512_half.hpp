@@ -107,6 +107,9 @@ __device__ __forceinline__ void half_transpose_1_2(double (&x)[4]) {
 #ifndef TFHE_AMD_HALF_PIN
 #define TFHE_AMD_HALF_PIN 1
 #endif
+#ifndef TFHE_AMD_HALF_TW_AHEAD
+#define TFHE_AMD_HALF_TW_AHEAD 1
+#endif
 __device__ __forceinline__ void bf_ct2(double& a0, double& b0, double w0, double wp0, double& a1, double& b1, double w1,
                                        double wp1, double p) {
     if (!TFHE_AMD_HALF_PIN) {
@@ -180,8 +183,23 @@ __device__ __forceinline__ void half_forward_small(double (&x)[4], const double 
         x[k] = a + t;
         x[k + 2] = a - t;
     }
-    Tw3 t;
+    Tw3 t, t2;
     load_tw3(t, s_tw + 3 * (half_row_offset(1) + half_row<1>(h, lane)));
+    if (TFHE_AMD_HALF_TW_AHEAD) {
+        // LDS instructions complete in issue order: a group's twiddle row is requested one group ahead,
+        // in front of the exchange that precedes the group, so that the group waits for the exchange only
+        load_tw3(t2, s_tw + 3 * (half_row_offset(2) + half_row<2>(h, lane)));
+        bf_ct2(x[0], x[1], t.w[1], t.wp[1], x[2], x[3], t.w[2], t.wp[2], p);
+        half_transpose_1_2(x);
+        load_tw3(t, s_tw + 3 * (half_row_offset(3) + half_row<3>(h, lane)));
+        ct4<false>(x, t2, p, pinv);
+        half_transpose<2, 3>(x, tr, lane);
+        load_tw3(t2, s_tw + 3 * (half_row_offset(4) + half_row<4>(h, lane)));
+        ct4<false>(x, t, p, pinv);
+        half_transpose<3, 4>(x, tr, lane);
+        ct4<true>(x, t2, p, pinv);
+        return;
+    }
     bf_ct2(x[0], x[1], t.w[1], t.wp[1], x[2], x[3], t.w[2], t.wp[2], p);
 
     half_transpose_1_2(x);
@@ -240,6 +258,28 @@ __device__ __forceinline__ void parity_inverse(double (&x)[4], const NttUniform&
     const double p = u.p, pinv = u.pinv;
     Tw3 t;
     load_tw3(t, s_rows + 3 * (parity_row_offset(64) + lane));
+    if (TFHE_AMD_HALF_TW_AHEAD) {  // every row one group ahead, as in half_forward_small
+        Tw3 t2;
+        load_tw3(t2, s_rows + 3 * (parity_row_offset(16) + (lane >> 2)));
+        gs4_near(x, t, p);
+        gs4_far(x, t, p);
+        x[0] = reduce(x[0], p, pinv);
+        half_transpose<4, 3>(x, tr, lane);
+        load_tw3(t, s_rows + 3 * (parity_row_offset(4) + (lane >> 4)));
+        gs4_near(x, t2, p);
+        reduce_0_2(x, p, pinv);
+        gs4_far(x, t2, p);
+        half_transpose<3, 2>(x, tr, lane);
+        load_tw3(t2, s_rows + 3 * parity_row_offset(1));
+        gs4_near(x, t, p);
+        reduce_0_2(x, p, pinv);
+        gs4_far(x, t, p);
+        half_transpose_1_2(x);
+        gs4_near(x, t2, p);
+        reduce_0_2(x, p, pinv);
+        gs4_far(x, t2, p);
+        return;
+    }
     gs4_near(x, t, p);
     gs4_far(x, t, p);
     x[0] = reduce(x[0], p, pinv);
