@@ -87,6 +87,9 @@ struct WgNtt {
 #ifndef TFHE_AMD_WG_EXPERIMENT
 #define TFHE_AMD_WG_EXPERIMENT 0
 #endif
+#ifndef TFHE_AMD_WG_PIPE_EXCHANGE
+#define TFHE_AMD_WG_PIPE_EXCHANGE -1  // -1: where it was measured to pay (forward_many), 0 / 1: never / always
+#endif
     // timing experiments (wrong results): 1 = every thread reads twiddle row 0 of its group,
     // 2 = no twiddle loads (thread-uniform values), 3 = no block barrier in the transposes,
     // 4 = no transposition at all, 5 = every key tile read from the first tile's address (wg_kernels.hip),
@@ -268,9 +271,21 @@ struct WgNtt {
             __builtin_amdgcn_sched_barrier(0);
             Tw7 tw;
             load_row(tw, group_rows<LDS_LEVEL>(table, lds_rows, 0, g), opaque(t >> base(g)), u);
+            // Pipelined form: the exchange of transform m + 1 is issued before the butterflies of transform m,
+            // which then cover it (a wave's LDS instructions complete in issue order, so one buffer serves
+            // back-to-back exchanges; the block-level ones alternate two buffers as before).  Measured on
+            // 4,096 / 2,048 gates: N = 1024, K = 1, L = 2 47.4 -> 43.9 ms; N = 1024 with L = 3 or K = 2 and
+            // N = 2048 1 - 2 % slower (the other workgroup of the CU already covers the exchange there, and
+            // the longer live ranges cost registers), so only pairs of N = 1024 transforms use it.
+            constexpr bool kPipe = TFHE_AMD_WG_PIPE_EXCHANGE < 0 ? (LOGN == 10 && M == 2) : TFHE_AMD_WG_PIPE_EXCHANGE != 0;
+            if (kPipe) transpose(xs[0], bufs, parity, g - 1, g, t);
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                transpose(xs[m], bufs, parity, g - 1, g, t);
+                if (kPipe) {
+                    if (m + 1 < M) transpose(xs[m + 1], bufs, parity, g - 1, g, t);
+                } else {
+                    transpose(xs[m], bufs, parity, g - 1, g, t);
+                }
                 constexpr bool kAlways = SMALL == 0;
                 if (g == GROUPS - 1) {
                     ct_group<LAST, true>(xs[m], tw, p, pinv);
