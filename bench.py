@@ -227,8 +227,9 @@ def extra_n2048(tfhe_amd, torch, np, dev_index):
 
 
 def extra_adders(tfhe_amd, torch, np, ctx, enc, dev):
-    """The 32-bit ripple-carry adder, gates batched per dependency level: the NAND-only netlist
-    (9 gates per bit) and the XOR/MUX one; operands encrypted, sum decrypted and compared."""
+    """The 32-bit adder, gates batched per dependency level: the NAND-only ripple-carry netlist
+    (9 gates per bit), the XOR/MUX ripple-carry one, and the parallel-prefix one (7 levels of wide
+    batches instead of 33 narrow ones); operands encrypted, sum decrypted and compared."""
     from tfhe_amd import circuit as CC
 
     res, wrong_total = {}, 0
@@ -237,7 +238,7 @@ def extra_adders(tfhe_amd, torch, np, ctx, enc, dev):
     bits = lambda v: np.array([(v >> i) & 1 for i in range(32)])  # noqa: E731
     backend = CC.DeviceBackend(ctx)
     n1 = ctx.params.n1
-    for name, build in (("nand_only", CC.ripple_carry_adder), ("xor_mux", CC.mux_adder)):
+    for name, build in (("nand_only", CC.ripple_carry_adder), ("xor_mux", CC.mux_adder), ("prefix", CC.prefix_adder)):
         gates, n_wires, aw, bw, zero, sums, cout = build(32)
         plan = CC.Plan(gates, n_wires)
         wires = np.zeros((n_wires, n1), dtype=np.uint32)

@@ -136,3 +136,47 @@ def test_loop_detection_still_works():
         C.levelize([(2, 0, 3, "xor"), (3, 1, 2, "mux", 0)], 4)
     with pytest.raises(ValueError):
         C.normalize((1, 0, 0, "frob"))
+
+
+def test_prefix_adder_shape_and_plaintext_sum():
+    """The parallel-prefix adder: log2(bits) + 2 levels, no dead gates, and the sum of every pair of a
+    random sample of operands (plaintext evaluation of the netlist)."""
+    gates, n_wires, a, b, zero, sums, cout = C.prefix_adder(32)
+    levels = C.levelize(gates, n_wires)
+    assert len(levels) == 5 + 2
+    assert len(C.prune(gates, sums + [cout])) == len(gates)
+    names = {v: k for k, v in B.GATES.items()}
+
+    class Plain:
+        def gates(self, ops, x, y):
+            return np.stack([O.GATE_TRUTH[names[int(o)]](u, v) for o, u, v in zip(ops, x, y)]).astype(np.uint32)
+
+        def mux(self, s, x1, x0):
+            return np.where(s == 1, x1, x0)
+
+    rs = np.random.RandomState(4)
+    cases = [(0, 0), (2**32 - 1, 1), (2**32 - 1, 2**32 - 1), (0x55555555, 0xAAAAAAAA), (0x0000FFFF, 1)]
+    cases += [(int(rs.randint(0, 2**32, dtype=np.uint64)), int(rs.randint(0, 2**32, dtype=np.uint64))) for _ in range(20)]
+    for x, y in cases:
+        w = np.zeros((n_wires, 1), dtype=np.uint32)
+        for i in range(32):
+            w[a[i], 0], w[b[i], 0] = (x >> i) & 1, (y >> i) & 1
+        C.evaluate(gates, w, Plain())
+        got = sum(int(w[s_, 0]) << i for i, s_ in enumerate(sums)) + (int(w[cout, 0]) << 32)
+        assert got == x + y, (x, y)
+
+
+def test_encrypted_prefix_adder_with_oracle(toy):
+    p, s0, ctx = toy
+    bits = 8
+    gates, n_wires, a, b, zero, sums, cout = C.prefix_adder(bits)
+    assert len(C.levelize(gates, n_wires)) == 3 + 2
+    r = O.rng(10)
+    for x, y in [(200, 100), (255, 255), (0, 0), (170, 85)]:
+        w = np.zeros((n_wires, p.n + 1), dtype=np.uint32)
+        w[a] = O.encrypt_bits([(x >> i) & 1 for i in range(bits)], s0, p, r)
+        w[b] = O.encrypt_bits([(y >> i) & 1 for i in range(bits)], s0, p, r)
+        C.evaluate(gates, w, OracleBackend(ctx))
+        got = sum(int(v) << i for i, v in enumerate(O.decrypt_bits(w[sums], s0, p)))
+        got += int(O.decrypt_bits(w[[cout]], s0, p)[0]) << bits
+        assert got == x + y

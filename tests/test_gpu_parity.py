@@ -287,6 +287,42 @@ def test_mux_adder_32_bits_on_device(keys, ctx, octx):
     assert total == x + y
 
 
+def test_prefix_adder_32_bits_on_device(keys, ctx, octx):
+    """32-bit parallel-prefix adder (AND / XOR / MUX gates, 7 levels of up to 95 gates), every level one
+    batched device call; every wire equals the oracle run in the same level order, sum correct."""
+    import torch
+    from tfhe_amd import circuit as C
+
+    p, s0, _, _, _ = keys
+    bits = 32
+    gates, n_wires, a, b, zero, sums, cout = C.prefix_adder(bits)
+    levels = C.levelize(gates, n_wires)
+    assert len(levels) == 7
+    rs = np.random.RandomState(12)
+    x, y = int(rs.randint(0, 2**32, dtype=np.uint64)), int(rs.randint(0, 2**32, dtype=np.uint64))
+    r = O.rng(34)
+    w = np.zeros((n_wires, p.n + 1), dtype=np.uint32)
+    w[a] = O.encrypt_bits([(x >> i) & 1 for i in range(bits)], s0, p, r)
+    w[b] = O.encrypt_bits([(y >> i) & 1 for i in range(bits)], s0, p, r)
+    dw = torch.from_numpy(w.view(np.int32).copy()).cuda()
+    C.evaluate(gates, dw, C.DeviceBackend(ctx), levels)
+    torch.cuda.synchronize()
+    got = dw.cpu().numpy().view(np.uint32)
+
+    class OracleBackend:
+        def gates(self, ops, u, v):
+            return octx.gate_batch(np.asarray(ops, dtype=np.uint8), u, v)
+
+        def mux(self, s, x1, x0):
+            return octx.mux_batch(s, x1, x0)
+
+    C.evaluate(gates, w, OracleBackend(), levels)
+    assert np.array_equal(got, w)
+    total = sum(int(v) << i for i, v in enumerate(O.decrypt_bits(got[sums], s0, p)))
+    total += int(O.decrypt_bits(got[[cout]], s0, p)[0]) << bits
+    assert total == x + y
+
+
 # ---- the 65,536-gate configuration at full size on one GPU ---------------------------------------
 
 def test_config3_65536_gates_decrypt_and_sampled_parity(keys, ctx, octx):

@@ -128,6 +128,65 @@ def mux_adder(bits):
     return gates, nxt, a, b, zero, sums, cin
 
 
+def prune(gates, outputs):
+    """The gates that some wire of `outputs` depends on, in their original order."""
+    norm = [normalize(g) for g in gates]
+    driver = {o: g for g, (o, _, _) in enumerate(norm)}
+    keep, stack = set(), [driver[w] for w in outputs if w in driver]
+    while stack:
+        g = stack.pop()
+        if g in keep:
+            continue
+        keep.add(g)
+        stack.extend(driver[w] for w in norm[g][2] if w in driver)
+    return [gates[g] for g in sorted(keep)]
+
+
+def prefix_adder(bits):
+    """Parallel-prefix (Kogge-Stone) adder: the same sum as the ripple-carry netlists in
+    log2(bits) + 2 levels instead of bits + 2, at the price of more gates per level -- which a
+    batched bootstrap evaluates in the time of one.
+        level 1:            g_i = a_i and b_i,  p_i = a_i xor b_i
+        distance d = 1, 2, 4, ...:   G_i = P_i ? G_(i-d) : G_i,   P_i = P_i and P_(i-d)     (i >= d)
+        last level:         sum_i = p_i xor G_(i-1)   (sum_0 = p_0),   carry out = G_(bits-1)
+    A group's generate and propagate signals are never both 1, so "G or (P and G')" is the MUX
+    above: one gate level per distance.  Gates that no output depends on are dropped.  Same return
+    layout as ripple_carry_adder (the `zero` wire is unused)."""
+    a = list(range(bits))
+    b = list(range(bits, 2 * bits))
+    zero = 2 * bits
+    nxt = 2 * bits + 1
+    gates = []
+
+    def new():
+        nonlocal nxt
+        nxt += 1
+        return nxt - 1
+
+    g, prop = [], []
+    for i in range(bits):
+        gi, pi = new(), new()
+        gates += [(gi, a[i], b[i], "and"), (pi, a[i], b[i], "xor")]
+        g.append(gi)
+        prop.append(pi)
+    G, P = list(g), list(prop)
+    d = 1
+    while d < bits:
+        G2, P2 = list(G), list(P)
+        for i in range(d, bits):
+            G2[i], P2[i] = new(), new()
+            gates += [(G2[i], P[i], G[i - d], "mux", G[i]), (P2[i], P[i], P[i - d], "and")]
+        G, P = G2, P2
+        d *= 2
+    sums = [prop[0]]
+    for i in range(1, bits):
+        s = new()
+        gates.append((s, prop[i], G[i - 1], "xor"))
+        sums.append(s)
+    cout = G[bits - 1]
+    return prune(gates, sums + [cout]), nxt, a, b, zero, sums, cout
+
+
 class HostBackend:
     """numpy rows through the host-pointer entry points: one call per gate type in a level."""
 
