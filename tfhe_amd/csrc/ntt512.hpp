@@ -384,15 +384,16 @@ struct TrPrio {
     __device__ __forceinline__ ~TrPrio() { if (TFHE_AMD_TR_SETPRIO) __builtin_amdgcn_s_setprio(0); }
 };
 
-// Slots of the exchange between layouts A and B.  A pad slot per 64 positions (slot = j + 8 (j >> 6))
-// keeps both sides free of bank conflicts: a 32-lane group of layout A reads 32 consecutive doubles,
-// one of layout B four runs of eight that start 72 doubles = 8 banks-of-doubles (mod 32) apart; the
-// 16-lane groups of the stores see the same pattern mod 16.  The pad slot per 8 positions that the
-// exchange between B and C needs (pad_pos) puts lanes 0..2 and 29..31 of a layout-A group on the same
-// banks: 1.25e9 conflict cycles per 8,192 gates, all of them from these two functions.
-// -DTFHE_AMD_TR_PAD_AB=0 selects that older form.
+// Slots of the exchange between layouts A and B.  Default (0): the pad slot per 8 positions of pad_pos,
+// shared with the exchange between B and C; it puts lanes 0..2 and 29..31 of a layout-A group on the
+// same banks (2-way conflicts: 240 extra LDS cycles per gate-step, the 1.25e9 SQ_LDS_BANK_CONFLICT per
+// 8,192 gates).  -DTFHE_AMD_TR_PAD_AB=1: a pad run of 8 slots per 64 positions (slot = j + 8 (j >> 6)),
+// free of conflicts on both sides.  Measured, same box: 8,192 gates 43.3 vs 43.5 ms (equal), 2,048 gates
+// 11.9 vs 11.7 ms, 1,024 gates (one wave per SIMD) 7.5 vs 7.0 ms -- the conflict-free form is slower
+// where a wave has its SIMD to itself, so the older pad stays: the conflicts cost LDS cycles the array
+// has to spare, while the other form changes how the compiler pairs the 8-byte accesses.
 #ifndef TFHE_AMD_TR_PAD_AB
-#define TFHE_AMD_TR_PAD_AB 1
+#define TFHE_AMD_TR_PAD_AB 0
 #endif
 __device__ __forceinline__ int ab_slot_a(int k, int lane) {
     return TFHE_AMD_TR_PAD_AB ? 72 * k + lane : pad_pos(64 * k + lane);

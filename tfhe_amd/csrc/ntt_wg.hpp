@@ -87,6 +87,9 @@ struct WgNtt {
 #ifndef TFHE_AMD_WG_EXPERIMENT
 #define TFHE_AMD_WG_EXPERIMENT 0
 #endif
+#ifndef TFHE_AMD_WG_TR_PAD
+#define TFHE_AMD_WG_TR_PAD 1  // per-exchange pad of the wave-private transpositions (0: one slot per 8 positions)
+#endif
 #ifndef TFHE_AMD_WG_PIPE_EXCHANGE
 #define TFHE_AMD_WG_PIPE_EXCHANGE -1  // -1: where it was measured to pay (forward_many), 0 / 1: never / always
 #endif
@@ -125,7 +128,7 @@ struct WgNtt {
             // side has a bank conflict (with the pad slot per 8 positions of pad_pos for every exchange,
             // a base above 3 put the ends of its 2^a-runs on the same banks).
             const int a = (base(from) > base(to) ? base(from) : base(to)) < 3 ? 3 : (base(from) > base(to) ? base(from) : base(to));
-            auto slot = [a](int j) { return TFHE_AMD_TR_PAD_AB ? j + ((j >> a) << (a - 3)) : pad_pos(j); };
+            auto slot = [a](int j) { return TFHE_AMD_WG_TR_PAD ? j + ((j >> a) << (a - 3)) : pad_pos(j); };
 #pragma unroll
             for (int k = 0; k < 8; k++) wb[slot(position(from, t, k) & 511)] = x[k];
             wave_lds_fence();
