@@ -210,34 +210,92 @@ __device__ __forceinline__ uint32_t torus_from_double_fast(double d) {
     return t >= 4294967296.0 ? 0u : (uint32_t)t;
 }
 
-// Eight conversions at once, three FP64 instructions each.  f = d - floor(d) as above (round to
-// nearest), then f + 1.5 * 2^20 with the FP64 rounding mode set to "toward zero" for just those
-// additions: the sum lies in [1.5 * 2^20, 1.5 * 2^20 + 1], where a double's unit is 2^-32, so its low
-// mantissa word is floor(f * 2^32) mod 2^32 (f = 1 gives 2^32, i.e. 0, like the reference's
-// conversion through 64 bits).  The mode is bits 3:2 of the MODE register and is restored inside
-// the same instruction block.
-__device__ __forceinline__ void torus_from_double_8(uint32_t (&out)[8], const double (&d)[8]) {
-    double f[8], s[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) f[i] = d[i] - __builtin_floor(d[i]);
-    const double c = 1572864.0;  // 1.5 * 2^20
+// Sixteen conversions at once.  In full: f = d - floor(d) as above (round to nearest), then
+// f + 1.5 * 2^20 with the FP64 rounding mode set to "toward zero" for just those additions: the sum
+// lies in [1.5 * 2^20, 1.5 * 2^20 + 1], where a double's unit is 2^-32, so its low mantissa word is
+// floor(f * 2^32) mod 2^32 (f = 1 gives 2^32, i.e. 0, like the reference's conversion through 64
+// bits).  The mode is bits 3:2 of the MODE register and is restored inside the same instruction block.
+//
+// f itself is needed only for -1/2 < d < 0: everywhere else d - floor(d) is exact (for |d| >= 1/2 the
+// fraction has no bit below 2^-53; for d >= 0 below 1 it is d), and then the truncated sum
+// d + 1.5 * 2^20 already has floor(d * 2^32) mod 2^32 = floor(f * 2^32) in its low word (|d| < 2^19 here:
+// at most N * 2^7 = 2^16).  Only in (-1/2, 0) can the reference's rounded 1 + d land on the next multiple
+// of 2^-32.  Such values are rare (d spreads over +-2^15), so a wave tests for them first -- the high
+// word of a double in [-0, -1/2) is, as a signed integer, below INT_MIN + 0x3FE00000 -- and takes the
+// subtraction only when one of its 1,024 values needs it: one FP64 instruction per value instead of
+// three.  Measured: 8,192 gates 68.5 -> 67.0 ms, 2,048 gates 19.3 -> 18.25 ms.  Checked against the
+// reference's formula on the device by tests/hip/convert_check.hip.
+// -DTFHE_AMD_REPLICA_FAST_CONVERT=0: the subtraction always.
+#ifndef TFHE_AMD_REPLICA_FAST_CONVERT
+#define TFHE_AMD_REPLICA_FAST_CONVERT 1
+#endif
+__device__ __forceinline__ void rtz_add_8(double (&d)[8], double c) {
     asm volatile(
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3\n\t"
         "s_nop 1\n\t"
-        "v_add_f64 %0, %8, %16\n\t"
-        "v_add_f64 %1, %9, %16\n\t"
-        "v_add_f64 %2, %10, %16\n\t"
-        "v_add_f64 %3, %11, %16\n\t"
-        "v_add_f64 %4, %12, %16\n\t"
-        "v_add_f64 %5, %13, %16\n\t"
-        "v_add_f64 %6, %14, %16\n\t"
-        "v_add_f64 %7, %15, %16\n\t"
+        "v_add_f64 %0, %0, %8\n\t"
+        "v_add_f64 %1, %1, %8\n\t"
+        "v_add_f64 %2, %2, %8\n\t"
+        "v_add_f64 %3, %3, %8\n\t"
+        "v_add_f64 %4, %4, %8\n\t"
+        "v_add_f64 %5, %5, %8\n\t"
+        "v_add_f64 %6, %6, %8\n\t"
+        "v_add_f64 %7, %7, %8\n\t"
         "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\t"
         "s_nop 1"
-        : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7])
-        : "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]), "s"(c));
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7])
+        : "s"(c));
+}
+// sixteen conversions (both parts of eight products); a and b are overwritten
+__device__ __forceinline__ void torus_from_double_16(uint32_t (&oa)[8], uint32_t (&ob)[8], double (&a)[8], double (&b)[8]) {
+    if (TFHE_AMD_REPLICA_FAST_CONVERT) {
+        int m = min(__double2hiint(a[0]), __double2hiint(b[0]));
 #pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = (uint32_t)__double2loint(s[i]);
+        for (int i = 1; i < 8; i++) m = min(m, min(__double2hiint(a[i]), __double2hiint(b[i])));
+        // The rare path sits inside one instruction block, behind a branch the compiler does not see
+        // (as control flow of the kernel it cost 108 bytes of spills at this kernel's 254 registers):
+        // skipped unless some lane of the wave holds a value in [-0, -1/2).
+        double t;
+        asm volatile(
+            "v_cmp_gt_i32 vcc, %18, %17\n\t"
+            "s_nop 1\n\t"
+            "s_cbranch_vccz .Ltfhe_cvt_skip_%=\n\t"
+            "v_floor_f64 %16, %0\n\tv_add_f64 %0, %0, -%16\n\t"
+            "v_floor_f64 %16, %1\n\tv_add_f64 %1, %1, -%16\n\t"
+            "v_floor_f64 %16, %2\n\tv_add_f64 %2, %2, -%16\n\t"
+            "v_floor_f64 %16, %3\n\tv_add_f64 %3, %3, -%16\n\t"
+            "v_floor_f64 %16, %4\n\tv_add_f64 %4, %4, -%16\n\t"
+            "v_floor_f64 %16, %5\n\tv_add_f64 %5, %5, -%16\n\t"
+            "v_floor_f64 %16, %6\n\tv_add_f64 %6, %6, -%16\n\t"
+            "v_floor_f64 %16, %7\n\tv_add_f64 %7, %7, -%16\n\t"
+            "v_floor_f64 %16, %8\n\tv_add_f64 %8, %8, -%16\n\t"
+            "v_floor_f64 %16, %9\n\tv_add_f64 %9, %9, -%16\n\t"
+            "v_floor_f64 %16, %10\n\tv_add_f64 %10, %10, -%16\n\t"
+            "v_floor_f64 %16, %11\n\tv_add_f64 %11, %11, -%16\n\t"
+            "v_floor_f64 %16, %12\n\tv_add_f64 %12, %12, -%16\n\t"
+            "v_floor_f64 %16, %13\n\tv_add_f64 %13, %13, -%16\n\t"
+            "v_floor_f64 %16, %14\n\tv_add_f64 %14, %14, -%16\n\t"
+            "v_floor_f64 %16, %15\n\tv_add_f64 %15, %15, -%16\n\t"
+            ".Ltfhe_cvt_skip_%=:"
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+              "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "=&v"(t)
+            : "v"(m), "s"((int)(0x80000000u + 0x3FE00000u))
+            : "vcc");
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            a[i] = a[i] - __builtin_floor(a[i]);
+            b[i] = b[i] - __builtin_floor(b[i]);
+        }
+    }
+    const double c = 1572864.0;  // 1.5 * 2^20
+    rtz_add_8(a, c);
+    rtz_add_8(b, c);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        oa[i] = (uint32_t)__double2loint(a[i]);
+        ob[i] = (uint32_t)__double2loint(b[i]);
+    }
 }
 
 }  // namespace tfhe_amd

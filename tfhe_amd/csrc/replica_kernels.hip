@@ -354,8 +354,7 @@ blind_rotate_512_replica_kernel(const d2* __restrict__ spec, const d2* __restric
                     vi[4 + k] = ad1 + bc1;
                 }
                 uint32_t tr_[8], ti_[8];
-                torus_from_double_8(tr_, vr);
-                torus_from_double_8(ti_, vi);
+                torus_from_double_16(tr_, ti_, vr, vi);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     lo[col][k] += tr_[k] + tr_[4 + k];
