@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 A/B: exchange pads (head vs oldpad), latency key prefetch depth, stamps of the N = 2048 kernel
+# A/B: exchange pads (head vs oldpad), latency key prefetch depth, stamps of the N = 2048 kernel
 cd "$GRAFT_REPO_ROOT"
 L=gpurun_out/r3/ab1.log; mkdir -p gpurun_out/r3; : > $L
 run() { echo "== $1: $3" >> $L; lib=$PWD/build/libtfhe_amd_$1.so; [ "$1" = head ] && lib=$PWD/tfhe_amd/libtfhe_amd.so
