@@ -265,6 +265,12 @@ def extra_adders(tfhe_amd, torch, np, ctx, enc, dev):
 
 
 def main_rank(args):
+    # Rank 0's standard output carries exactly one line, the JSON line: whatever a library prints there
+    # while the ranks set up (gloo announces its connections on stdout, for one) goes to standard error.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -494,7 +500,8 @@ def main_rank(args):
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(p, args.cpu_sample_gates, threads)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
