@@ -297,3 +297,53 @@ def test_bench_single_rank_through_rccl():
     assert line["distributed"]["backend"] == "nccl" and line["distributed"]["world_size"] == 1
     assert line["distributed"]["key_broadcast_s"] > 0.0
     assert line["verified"] == {**line["verified"], "gates_decrypted": 160, "wrong": 0}
+
+
+def _rccl_worker(port, n_gates, q):
+    """distributed.broadcast_keys and nand_sharded over an RCCL process group of one rank: device
+    tensors through the real backend (two RCCL ranks cannot share one GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    import tfhe_amd
+    from tfhe_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        p = O.params_default()
+        s0, sr, bk, ks = O.keyset(p, seed=4321)
+        bits_a, bits_b, a, b = _inputs(p, s0, n_gates, seed=35)
+        bk_t, ks_t = D.broadcast_keys(p, bk, ks, src=0, device=dev)   # device tensors over RCCL
+        assert bk_t.is_cuda and ks_t.is_cuda
+        ctx = tfhe_amd.Context(tfhe_amd.params_default(), bk_t, ks_t, device=0, keys_on_device=True)
+
+        def evaluate(x, y):
+            out = torch.empty_like(x)
+            ctx.nand_device(x, y, out, stream=torch.cuda.current_stream(dev))
+            return out
+
+        a_t = torch.from_numpy(a.view(np.int32)).to(dev)
+        b_t = torch.from_numpy(b.view(np.int32)).to(dev)
+        full = D.nand_sharded(evaluate, a_t, b_t, n_gates, p.n + 1, src=0, device=dev)
+        torch.cuda.synchronize(dev)
+        ctx.close()
+        want = O.Context(p, bk, ks).nand_batch(a, b)
+        q.put(bool(np.array_equal(full.cpu().numpy().view(np.uint32), want)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_over_rccl_single_rank():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_rccl_worker, args=(_free_port(), 9, q))
+    pr.start()
+    pr.join(240)
+    assert pr.exitcode == 0
+    assert q.get(timeout=5) is True
