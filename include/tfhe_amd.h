@@ -139,7 +139,8 @@ int tfhe_amd_nand_batch_device(tfhe_amd_ctx* ctx, const uint32_t* a, const uint3
  * inputs and the lv1 ciphertexts, (n+1) + (N*K+1) words per gate) is a static device array of
  * TFHE_AMD_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.
  * Batches whose workspace exceeds it (more than 2,523 gates at the default parameters) are rejected
- * with TFHE_AMD_ERR_ARGUMENT.  All contexts on one GPU share that GPU's array, which keeps the last
+ * with TFHE_AMD_ERR_ARGUMENT, and so are parameter sets whose ring does not fit LDS (N > 2048: their
+ * kernels take a workspace per launch; TFHE_AMD_ERR_UNSUPPORTED).  All contexts on one GPU share that GPU's array, which keeps the last
  * call's contents.  Calls through this entry point on one GPU are ordered one behind the other even
  * on different streams (an event created with the first context on that GPU: recording it and
  * waiting for it allocate nothing).  Two cases stay with the caller: a call on a stream under

@@ -118,3 +118,18 @@ def test_noalloc_allocates_nothing_and_is_capturable():
         ctx.nand_device_noalloc(a, b, out)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want[0])
+
+
+def test_noalloc_rejects_sets_that_need_a_launch_workspace():
+    """A ring beyond LDS (N = 4096) runs on kernels that take a workspace per launch: the entry point that
+    allocates nothing refuses it, the allocating one evaluates it."""
+    p = tfhe_amd.Params(2, 4096, 1, 8, 1, 2, 2)
+    bk, ks = _rand(p.bk_shape(), 3), _rand(p.ks_shape(), 4)
+    dev = torch.device("cuda", 0)
+    with tfhe_amd.Context(p, bk, ks, device=0) as ctx:
+        a = torch.from_numpy(_rand((2, p.n1), 5).view(np.int32)).to(dev)
+        out = torch.empty_like(a)
+        with pytest.raises(TfheAmdError, match="per-launch workspace"):
+            ctx.nand_device_noalloc(a, a, out)
+        ctx.nand_device(a, a, out)
+        ctx.synchronize()

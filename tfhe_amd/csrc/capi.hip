@@ -1020,6 +1020,12 @@ int tfhe_amd_nand_batch_device_noalloc(tfhe_amd_ctx* ctx, const uint32_t* a, con
                                                std::to_string(kNoAllocWords / per_gate) +
                                                " gates at this parameter set); use tfhe_amd_nand_batch_device");
     if (!ctx->scratch || !ctx->scratch->ptr) return fail(TFHE_AMD_ERR_HIP, "static workspace unresolved on this device");
+    // rings whose per-gate state does not fit LDS run on kernels that take a workspace per launch
+    // (run_blind_rotate allocates it stream-ordered): not through this entry point
+    if (!ctx->replica && !ctx->fast && !ctx->wg &&
+        generic_big_workspace_words(n_gates, ctx->p.N, ctx->p.K, ctx->p.L) != 0)
+        return fail(TFHE_AMD_ERR_UNSUPPORTED, "this parameter set's blind rotation needs a per-launch workspace; "
+                                              "use tfhe_amd_nand_batch_device");
     DeviceGuard guard(ctx->device);
     hipStream_t s = pick_stream(ctx, stream);
     ScratchState& st = *ctx->scratch;
